@@ -1,0 +1,183 @@
+#!/usr/bin/env python
+"""bench.py - cells embedded / s for the 2-layer WGNN forward (BASELINE.json metric) on N MI355X.
+
+A "step" = one full 2-layer forward (L1 genes<-cells, L1 cells<-genes, L2 cells<-genes, projections, head)
+over one synthetic graph already resident in HBM.  N = 1: BASELINE cfg3 (100k cells x 20k genes,
+dense_dim 400, hidden 256, 16 classes).  N > 1: weak scaling - every rank owns a cfg3-sized cell shard
+(N*100k cells in total; at N = 8 that is BASELINE cfg5's scale), gene table replicated, ONE data-path
+collective per forward (all-reduce of the [G,H] gene partial sums) + the logits all-gather.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
+algorithmic bytes / HIP-event launch time) and `cpu_baseline` (the CPU restatement timed on this host).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def pass_bytes(nnz, R, S, D, G, s=4):
+    """Algorithmic HBM bytes of ONE aggregation launch: CSR col+val once, rowptr,
+    every source row once, every self row once, alpha, output once."""
+    return 8 * nnz + 4 * (R + 1) + s * D * (S + R) + 4 * G + s * D * R
+
+
+def cpu_baseline(graph, model, feats_g, feats_c, gpu_logits, cfg):
+    """Times the CPU restatement (oracle/: C + OpenMP aggregation in the reference's arithmetic order,
+    torch nn.Linear for the dense part like the reference on CPU) on this host.  The reference itself
+    cannot run (DGL 0.4.3 absent) so kind = "port".  Also returns GPU-vs-CPU max abs error at full size."""
+    import numpy as np
+    import scipy.sparse as sp
+    from oracle import c_oracle as CO, wgnn_oracle as O
+    G, C = graph.num_genes, graph.num_cells
+    cg = graph.cg
+    # the oracle gets the SAME normalised operand (device K4 output), rebuilt as scipy CSR on the host
+    A_cg = sp.csr_matrix((cg.val.cpu().numpy(), cg.col.cpu().numpy(), cg.rowptr.cpu().numpy()), shape=(C, G))
+    gc = graph.gc
+    A_gc = sp.csr_matrix((gc.val.cpu().numpy(), gc.col.cpu().numpy(), gc.rowptr.cpu().numpy()), shape=(G, C))
+    ocg = O.CsrGraph(G, C, A_cg, A_gc, np.diff(A_cg.indptr) + 1, np.diff(A_gc.indptr) + 1)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    feats = np.concatenate([feats_g.cpu().numpy(), feats_c.cpu().numpy()])
+    reps, t_best, logits = 0, 1e30, None
+    t_all = time.perf_counter()
+    while reps < 3 and (time.perf_counter() - t_all) < 25.0:
+        t0 = time.perf_counter()
+        logits = CO.forward(sd, ocg, feats, model.n_layers)
+        t_best = min(t_best, time.perf_counter() - t0); reps += 1
+    err = float(np.abs(logits - gpu_logits.cpu().numpy()).max())
+    return {"value": round(C / t_best, 1), "unit": "cells/s", "cores": CO.num_threads(), "kind": "port",
+            "sample": f"full {cfg.name} graph ({C} cells), best of {reps} forward(s), {t_best:.2f} s each; "
+                      f"C/OpenMP aggregation + torch Linear; host has {os.cpu_count()} logical CPUs",
+            "gpu_vs_cpu_max_abs_err": err}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default=os.environ.get("WGNN_BENCH_CONFIG", "cfg3"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0)); local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import scdeepsort_amd as sda
+    from scdeepsort_amd import ops, synthetic as S
+    from scdeepsort_amd.sharded import ShardedWgnn
+
+    cfg = S.CONFIGS[args.config]
+    G, C = cfg.genes, cfg.cells                     # C = cells PER RANK (weak scaling)
+    t_setup = time.time()
+    rp, col, val = S.synth_expression(C, G, cfg.density, seed=S.REFERENCE_SEED + rank, device=dev)
+    torch.manual_seed(1234)
+    model = sda.GNN(cfg.dense_dim, cfg.hidden, cfg.n_classes, cfg.n_layers, G, activation=F.relu)
+    with torch.no_grad():
+        model.alpha.uniform_(0.5, 1.5)               # reference init is ones; exercise the alpha path
+    model = model.to(dev).eval()
+    feats_g = S.synth_features(G, cfg.dense_dim, seed=7, device=dev)
+    feats_c = S.synth_features(C, cfg.dense_dim, seed=100 + rank, device=dev)
+    engine = ShardedWgnn.build(model, rp, col, val, G)          # world == 1 -> plain single-GPU graph
+    del rp, col, val
+    torch.cuda.synchronize()
+    t_setup = time.time() - t_setup
+
+    def step():
+        with torch.no_grad():
+            return engine.forward(feats_g, feats_c)
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ops.PROFILE = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(out).all()
+    ms_per_step = dt / args.steps * 1e3
+    total_cells = C * world
+    value = total_cells / (dt / args.steps)
+
+    # ---- roofline of the dominant kernel (HIP events on the launch stream, averaged over the timed steps)
+    per = {}
+    for tag, e0, e1 in prof:
+        per.setdefault(tag, []).append(e0.elapsed_time(e1))
+    passes = []
+    for tag, ts in per.items():
+        d = dict(zip(tag[::2], tag[1::2]))
+        ms = sum(ts) / len(ts)
+        b = pass_bytes(d["nnz"], d["rows"], d["cols"], d["D"], G)
+        passes.append({"rows": d["rows"], "src_rows": d["cols"], "nnz": d["nnz"], "D": d["D"],
+                       "launches_per_step": len(ts) // args.steps, "avg_ms": round(ms, 4),
+                       "alg_bytes": b, "achieved_GBs": round(b / ms / 1e6, 1)})
+    passes.sort(key=lambda p: -p["avg_ms"] * p["launches_per_step"])
+    dom = passes[0]
+    traffic = None
+    tf = ROOT / "profiles" / "hbm_traffic.json"      # PMC-derived bytes/launch from a separate rocprofv3 --pmc run
+    if tf.exists():
+        try:
+            traffic = json.loads(tf.read_text()).get(f"{args.config}:{dom['rows']}x{dom['src_rows']}")
+        except Exception:
+            traffic = None
+    roofline = {"bound": "hbm", "kernel": f"agg_main (rows={dom['rows']}, src={dom['src_rows']}, D={dom['D']})",
+                "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "alg_bytes_per_launch": dom["alg_bytes"], "avg_launch_ms": dom["avg_ms"], "passes": passes,
+                "forward_alg_bytes": engine.forward_alg_bytes(cfg.dense_dim),
+                "forward_achieved_GBs": round(engine.forward_alg_bytes(cfg.dense_dim) / ms_per_step / 1e6, 1),
+                "note": "AI vs algorithmic bytes is 50-110 flop/B (> fp32 ridge ~20): the gather of nnz*D*4 B "
+                        "from L2/MALL and fp32 FMA issue bound this kernel before HBM does (DESIGN.md section 4)"}
+
+    # ---- CPU baseline: the restatement (C/OpenMP aggregation + torch Linear) on this host, rank 0, N = 1 only
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(engine.graph, model, feats_g, feats_c, out, cfg)
+
+    if rank == 0:
+        line = {"metric": "cells embedded/sec (2-layer WGNN fwd)", "value": round(value, 1), "unit": "cells/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"{cfg.name}: {C} cells/GPU x {G} genes, density {cfg.density}, "
+                                       f"dense_dim {cfg.dense_dim}, hidden {cfg.hidden}, {cfg.n_layers}-layer WGNN forward "
+                                       f"+ {cfg.n_classes}-class head", "cells_total": total_cells,
+                           "nnz_per_gpu": engine.nnz, "parallelism": f"cell-shard x{world}",
+                           "setup_s": round(t_setup, 1)},
+                "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

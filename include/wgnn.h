@@ -1,0 +1,168 @@
+/*
+ * wgnn.h - C ABI of the MI355X (gfx950) weighted-GNN aggregation library
+ *          (libwgnn_hip.so, built from scdeepsort_amd/csrc/).
+ *
+ * This is the drop-in boundary for scDeepSort's hot path.  The reference has no
+ * FFI of its own; the operator boundary it replaces is the Python call
+ *
+ *     nf.block_compute(i, self.message_func, fn.mean('m', 'neigh'), layer)
+ *                                                  (reference models/gnn.py:65)
+ *
+ * i.e. per-edge message  m_e = h[src]*alpha[k(e)]*w_e   (models/gnn.py:47-56),
+ * mean over in-edges incl. the self-loop  [DGL 0.4.3 fn.mean], then
+ * NodeUpdate = Linear + ReLU  (models/gnn.py:18-25), plus autograd's backward of
+ * the same (train.py:84) and the graph-operand normalisation
+ * normalize_weight (utils/preprocess_internal.py:15-23).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer into caller-owned memory unless the
+ *     parameter name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - functions enqueue work on `stream` and return immediately: they never
+ *     synchronise, never allocate persistent memory, never throw; they are
+ *     re-entrant across streams (scratch is passed in by the caller);
+ *   - return value: 0 = ok, negative = WGNN_ERR_* (see wgnn_last_error_string);
+ *   - CSR is destination-major: row r lists the in-edges of destination r,
+ *     `col` = source index, `val` = normalised edge weight.  Self-loops are
+ *     IMPLICIT (weight 1, added by the kernels), matching the reference's
+ *     "normalise, then add self-loops" order (preprocess_internal.py:211-214).
+ *   - feature matrices are row-major with a leading dimension in ELEMENTS;
+ *     D and every ld must be multiples of 4 (16-byte rows for f32).
+ */
+#ifndef WGNN_H_
+#define WGNN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WGNN_VERSION 100           /* 0.1.0 */
+
+/* error codes */
+#define WGNN_OK                 0
+#define WGNN_ERR_BAD_ARG       -1  /* NULL pointer / negative size / bad enum             */
+#define WGNN_ERR_ALIGNMENT     -2  /* D or ld not a multiple of 4, or pointer not 16-B aligned */
+#define WGNN_ERR_UNSUPPORTED   -3  /* dtype / width combination not built                  */
+#define WGNN_ERR_WORKSPACE     -4  /* workspace too small                                  */
+#define WGNN_ERR_LAUNCH        -5  /* hipLaunch / hipMemsetAsync failed                    */
+#define WGNN_ERR_PLAN          -6  /* plan blob malformed or built for another CSR         */
+
+/* which end of an edge is the gene (selects the alpha index rule, gnn.py:49-53) */
+#define WGNN_SRC_IS_GENE  0   /* gene->cell edges: k(e) = source gene id   (gnn.py:51); rows are cells  */
+#define WGNN_DST_IS_GENE  1   /* cell->gene edges: k(e) = dest   gene id   (gnn.py:52); rows are genes  */
+#define WGNN_NO_ALPHA     2   /* plain weighted sum (cell-feature build, preprocess_internal.py:197-199;
+                                 multi-GPU partial sums)                                                 */
+
+/* element types of feature matrices */
+#define WGNN_F32 0
+#define WGNN_F16 1            /* storage only; accumulation is always fp32 */
+
+/* flags for wgnn_agg_fwd */
+#define WGNN_FLAG_RELU     1u   /* out = max(out, 0) after bias (NodeUpdate activation, gnn.py:21-22)      */
+#define WGNN_FLAG_NO_MEAN  2u   /* skip the 1/(deg+1) division (partial sums that are all-reduced first)  */
+#define WGNN_FLAG_NO_SELF  4u   /* skip the self-loop term                                                */
+#define WGNN_FLAG_SELF_COMPACT 8u /* h_self holds one row per OUTPUT SLOT (h_self[i]) instead of per CSR row (h_self[r]);
+                                     used with row_ids for seed mini-batches (train.py:71-81)                */
+
+int         wgnn_version(void);
+const char* wgnn_last_error_string(int code);
+
+/* ---------------------------------------------------------------------------
+ * Execution plan: splits long rows into fixed-size chunks so that a hub gene
+ * with ~C in-edges does not serialise on one wavefront.  Built once per CSR
+ * (host side, from a host copy of rowptr) and uploaded by the caller.
+ *
+ *   items_host : int32[4 * n_items]  {row_slot, nnz_begin, nnz_end, partial_slot | -1}
+ *   long_host  : int32[4 * n_long]   {row_slot, first_partial_slot, n_partials, 0}
+ * `row_slot` indexes row_ids (or is the row itself when row_ids == NULL).
+ * Call once with items_host == NULL to obtain the counts.
+ * ------------------------------------------------------------------------- */
+int wgnn_plan_build_host(const int32_t* rowptr_host, const int32_t* row_ids_host, int64_t n_rows,
+                         int32_t chunk_nnz,
+                         int32_t* items_host, int32_t* long_host,
+                         int64_t* n_items, int64_t* n_long, int64_t* n_partials);
+
+/* ---------------------------------------------------------------------------
+ * K1  forward:  replaces message_func + fn.mean (+ optional bias/ReLU epilogue)
+ *               (models/gnn.py:47-56,65 and :20-22)
+ *
+ *   for each output slot i (row r = row_ids ? row_ids[i] : i):
+ *     SRC_IS_GENE: out[i] = ( sum_j val_j*alpha[col_j]*h_src[col_j] + alpha[self_idx]*h_self[r] ) * inv_deg[r]
+ *     DST_IS_GENE: out[i] = ( alpha[r]*sum_j val_j*h_src[col_j]    + alpha[self_idx]*h_self[r] ) * inv_deg[r]
+ *     NO_ALPHA   : out[i] = ( sum_j val_j*h_src[col_j] [+ h_self[r]] ) * inv_deg[r]
+ *   then  out[i] += bias (if bias) ; out[i] = relu(out[i]) (if WGNN_FLAG_RELU).
+ *   inv_deg == NULL  =>  1/(rowptr[r+1]-rowptr[r]+1)   (in-degree counts the self-loop).
+ *   self_idx is gene_num+1 for cell rows and gene_num for gene rows (gnn.py:42,49,53).
+ *
+ *   items/long_rows come from wgnn_plan_build_host (device copies).  `partials`
+ *   must hold n_partials*D floats (may be NULL when n_long == 0).
+ * ------------------------------------------------------------------------- */
+int wgnn_agg_fwd(const int32_t* rowptr, const int32_t* col, const float* val,
+                 const float* alpha, int alpha_mode, int32_t self_idx,
+                 const void* h_src, int64_t ld_src,
+                 const void* h_self, int64_t ld_self,
+                 const int32_t* row_ids, const float* inv_deg, const float* bias,
+                 void* out, int64_t ld_out,
+                 int64_t n_out, int32_t D, int dtype_in, int dtype_out, uint32_t flags,
+                 const int32_t* items, int64_t n_items,
+                 const int32_t* long_rows, int64_t n_long,
+                 float* partials, int64_t n_partials,
+                 void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K2  backward w.r.t. the source rows (autograd of K1, train.py:84):
+ *     runs over the TRANSPOSED structure (row s lists the destinations r that s feeds,
+ *     t_val = the same normalised weights re-ordered).
+ *
+ *     SRC_IS_GENE: T[s] = sum_r t_val*inv_deg[r]*g[r];  dh_src[s] (+)= alpha[s]*T[s];
+ *                  dalpha[s] (+)= <h_src[s], T[s]>      (if dalpha && h_src)
+ *     DST_IS_GENE: dh_src[s] (+)= sum_r t_val*alpha[r]*inv_deg[r]*g[r]
+ *     NO_ALPHA   : dh_src[s] (+)= sum_r t_val*inv_deg[r]*g[r]
+ *   `accumulate` != 0 adds into dh_src instead of overwriting.
+ *   inv_deg is REQUIRED here (it belongs to the destination rows).
+ * ------------------------------------------------------------------------- */
+int wgnn_agg_bwd_src(const int32_t* t_rowptr, const int32_t* t_col, const float* t_val,
+                     const float* alpha, int alpha_mode,
+                     const float* inv_deg_dst,
+                     const float* g, int64_t ld_g,
+                     const float* h_src, int64_t ld_src,
+                     float* dh_src, int64_t ld_dh, float* dalpha, int accumulate,
+                     int64_t n_src, int32_t D,
+                     const int32_t* items, int64_t n_items,
+                     const int32_t* long_rows, int64_t n_long,
+                     float* partials, int64_t n_partials,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K3  backward w.r.t. alpha for DST_IS_GENE rows and for the self-loop scalars:
+ *     dalpha_row[i]  = inv_deg[r] * < g[i], sum_j val_j*h_src[col_j] >       (DST_IS_GENE only, else untouched)
+ *     dself_row[i]   = inv_deg[r] * < g[i], h_self[r] >                      (per-row partial of dalpha[self_idx])
+ *   The caller adds dalpha_row into dalpha[r] and sums dself_row into dalpha[self_idx].
+ * ------------------------------------------------------------------------- */
+int wgnn_agg_bwd_alpha(const int32_t* rowptr, const int32_t* col, const float* val,
+                       const float* inv_deg, const int32_t* row_ids,
+                       const float* g, int64_t ld_g,
+                       const float* h_src, int64_t ld_src,
+                       const float* h_self, int64_t ld_self,
+                       float* dalpha_row, float* dself_row,
+                       int64_t n_out, int32_t D, uint32_t flags,   /* WGNN_FLAG_SELF_COMPACT only */
+                       const int32_t* items, int64_t n_items,
+                       const int32_t* long_rows, int64_t n_long,
+                       float* partials, int64_t n_partials,
+                       void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K4  graph-operand normalisation: normalize_weight (preprocess_internal.py:15-23)
+ *     val_out[j] = deg_r * val_in[j] / sum_{j in row r} val_in[j]      for rows with >= 1 entry
+ *     inv_deg[r] = 1 / (deg_r + 1)                                     (if inv_deg != NULL)
+ * ------------------------------------------------------------------------- */
+int wgnn_normalize_rows(const int32_t* rowptr, const float* val_in, float* val_out, float* inv_deg,
+                        int64_t n_rows, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WGNN_H_ */

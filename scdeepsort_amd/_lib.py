@@ -1,0 +1,57 @@
+"""ctypes binding of the C ABI declared in ``include/wgnn.h``.
+
+The product path has NO CPU fallback: if ``libwgnn_hip.so`` is missing the
+import of :func:`lib` raises, and every wrapper raises on a non-zero return.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from functools import lru_cache
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "libwgnn_hip.so"
+
+# error codes / enums (mirror include/wgnn.h)
+SRC_IS_GENE, DST_IS_GENE, NO_ALPHA = 0, 1, 2
+F32, F16 = 0, 1
+FLAG_RELU, FLAG_NO_MEAN, FLAG_NO_SELF, FLAG_SELF_COMPACT = 1, 2, 4, 8
+
+_vp, _i32, _i64, _u32, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_int
+
+SIGNATURES = {
+    "wgnn_version": (C.c_int, []),
+    "wgnn_last_error_string": (C.c_char_p, [C.c_int]),
+    "wgnn_plan_build_host": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "wgnn_agg_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _int, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
+                               _vp, _i64, _i64, _i32, _int, _int, _u32,
+                               _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "wgnn_agg_bwd_src": (C.c_int, [_vp, _vp, _vp, _vp, _int, _vp, _vp, _i64, _vp, _i64,
+                                   _vp, _i64, _vp, _int, _i64, _i32,
+                                   _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "wgnn_agg_bwd_alpha": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp,
+                                     _i64, _i32, _u32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "wgnn_normalize_rows": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
+}
+
+
+class WgnnError(RuntimeError):
+    pass
+
+
+@lru_cache(maxsize=1)
+def lib() -> C.CDLL:
+    if not LIB_PATH.exists():
+        raise WgnnError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -m scdeepsort_amd.build` or `__graft_entry__.build()`.")
+    dll = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(dll, name)          # AttributeError here = header/ABI drift
+        fn.restype, fn.argtypes = res, args
+    return dll
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().wgnn_last_error_string(rc).decode()
+        raise WgnnError(f"{what} failed: {msg} (code {rc})")

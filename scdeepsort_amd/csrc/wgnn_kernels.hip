@@ -1,0 +1,456 @@
+// wgnn_kernels.hip - CDNA4 (gfx950) kernels + C ABI for scDeepSort's weighted-mean aggregation.
+//
+// Replaces, for the hot path of the reference:
+//   GNN.message_func            models/gnn.py:47-56   (per-edge h[src]*alpha[k]*w)
+//   fn.mean('m','neigh')        models/gnn.py:65      (sum over in-edges / in-degree, DGL 0.4.3)
+//   NodeUpdate bias + ReLU      models/gnn.py:20-22   (fused epilogue; the GEMM is applied project-first)
+//   autograd backward of those  train.py:84
+//   normalize_weight            utils/preprocess_internal.py:15-23
+//
+// Design: destination-major CSR; one 64-lane wavefront owns one
+// row chunk ("item").  A feature row of D floats is covered by LPR lanes x float4
+// (16-byte, fully coalesced 1 KiB row reads at D=256); when D < 256 the 64/LPR
+// lane groups take different non-zeros of the same row and are folded with
+// xor-shuffles at the end.  Column index / weight of 64 non-zeros are fetched
+// with one coalesced load each and broadcast from registers (v_readlane /
+// ds_bpermute), alpha[k(e)] is folded into the weight once per edge, 1/(deg+1),
+// the implicit self-loop, bias and ReLU are fused into the epilogue.  Rows longer
+// than the plan's chunk size are split; their partial sums go to a caller-owned
+// scratch and are folded in a fixed order by a finalize kernel (deterministic,
+// no atomics).
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include "wgnn.h"
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+constexpr int kBlock = 64 * kWavesPerBlock;
+
+enum { EPI_FWD = 0, EPI_BWD_SRC = 1, EPI_BWD_ALPHA = 2 };
+
+struct KArgs {
+    const int* rowptr; const int* col; const float* val;
+    const float* cs1; const float* cs2;          // optional per-column scale factors (alpha[col], inv_deg[col])
+    const void* src; long ld_src;                // gathered rows
+    const float* alpha; int mode; int self_idx;
+    const void* self; long ld_self;              // EPI_FWD: h_self; EPI_BWD_SRC: h_src rows (for dalpha); EPI_BWD_ALPHA: h_self
+    const int* row_ids; const float* inv_deg; const float* bias;
+    void* out; long ld_out;
+    const float* g; long ld_g;                   // EPI_BWD_ALPHA: upstream gradient rows
+    float* aux1; float* aux2;                    // dalpha (BWD_SRC) / dalpha_row, dself_row (BWD_ALPHA)
+    int D; unsigned flags; int accumulate;
+    const int4* items; long n_items;
+    const int4* long_rows; long n_long;
+    float* partials;
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const __half* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    const __half2 a = *reinterpret_cast<const __half2*>(&u.x);
+    const __half2 b = *reinterpret_cast<const __half2*>(&u.y);
+    const float2 fa = __half22float2(a), fb = __half22float2(b);
+    return make_float4(fa.x, fa.y, fb.x, fb.y);
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(__half* p, float4 v) {
+    __half2 a = __floats2half2_rn(v.x, v.y), b = __floats2half2_rn(v.z, v.w);
+    uint2 u; u.x = *reinterpret_cast<unsigned*>(&a); u.y = *reinterpret_cast<unsigned*>(&b);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+__device__ __forceinline__ void fma4(float4& acc, float w, const float4& x) {
+    acc.x = fmaf(w, x.x, acc.x); acc.y = fmaf(w, x.y, acc.y);
+    acc.z = fmaf(w, x.z, acc.z); acc.w = fmaf(w, x.w, acc.w);
+}
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) {
+    return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+
+// sum over the LPR lanes of a lane group (all 64 lanes participate)
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+    for (int off = LPR / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// Shared epilogue: turns the accumulated neighbour sum of one row into the kernel's outputs.
+template <int LPR, int NV, typename TIn, typename TOut, int EPI>
+__device__ __forceinline__ void epilogue(const KArgs& a, float4 (&acc)[NV], int slot, int l, bool writer) {
+    const int r = a.row_ids ? a.row_ids[slot] : slot;
+    float invd = 1.0f;
+    if (!(a.flags & WGNN_FLAG_NO_MEAN)) {
+        invd = a.inv_deg ? a.inv_deg[r] : 1.0f / (float)(a.rowptr[r + 1] - a.rowptr[r] + 1);
+    }
+    if constexpr (EPI == EPI_FWD) {
+        const float rs = invd * (a.mode == WGNN_DST_IS_GENE ? a.alpha[r] : 1.0f);
+        const bool has_self = !(a.flags & WGNN_FLAG_NO_SELF) && a.self != nullptr;
+        const float sc = has_self ? invd * (a.mode == WGNN_NO_ALPHA ? 1.0f : a.alpha[a.self_idx]) : 0.0f;
+        const TIn* selfp = reinterpret_cast<const TIn*>(a.self) +
+                           (size_t)((a.flags & WGNN_FLAG_SELF_COMPACT) ? slot : r) * a.ld_self;
+        TOut* outp = reinterpret_cast<TOut*>(a.out) + (size_t)slot * a.ld_out;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c0 = (k * LPR + l) * 4;
+            if (writer && c0 < a.D) {
+                float4 o = acc[k];
+                o.x *= rs; o.y *= rs; o.z *= rs; o.w *= rs;
+                if (has_self) fma4(o, sc, ld4(selfp + c0));
+                if (a.bias) { const float4 b = ld4(a.bias + c0); o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w; }
+                if (a.flags & WGNN_FLAG_RELU) {
+                    o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
+                }
+                st4(outp + c0, o);
+            }
+        }
+    } else if constexpr (EPI == EPI_BWD_SRC) {
+        // slot == source row s.  acc = T[s] = sum_r t_val * colscale[r] * g[r]
+        const float rs = (a.mode == WGNN_SRC_IS_GENE) ? a.alpha[r] : 1.0f;
+        float* outp = reinterpret_cast<float*>(a.out) + (size_t)slot * a.ld_out;
+        float dot = 0.f;
+        const bool want_dalpha = (a.mode == WGNN_SRC_IS_GENE) && a.aux1 && a.self;
+        const float* hp = reinterpret_cast<const float*>(a.self) + (size_t)r * a.ld_self;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c0 = (k * LPR + l) * 4;
+            if (c0 < a.D) {
+                if (want_dalpha && writer) dot += dot4(acc[k], ld4(hp + c0));
+                if (writer) {
+                    float4 o = acc[k];
+                    o.x *= rs; o.y *= rs; o.z *= rs; o.w *= rs;
+                    if (a.accumulate) { const float4 p = ld4(outp + c0); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+                    st4(outp + c0, o);
+                }
+            }
+        }
+        if (want_dalpha) {                         // wave-uniform branch
+            dot = group_sum<LPR>(dot);
+            if (writer && l == 0) a.aux1[r] = (a.accumulate ? a.aux1[r] : 0.f) + dot;
+        }
+    } else {                                       // EPI_BWD_ALPHA: acc = S[i] = sum_j val_j h_src[col_j]
+        const float* gp = a.g + (size_t)slot * a.ld_g;
+        const float* sp = reinterpret_cast<const float*>(a.self) +
+                          (size_t)((a.flags & WGNN_FLAG_SELF_COMPACT) ? slot : r) * a.ld_self;
+        float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c0 = (k * LPR + l) * 4;
+            if (writer && c0 < a.D) {
+                const float4 gv = ld4(gp + c0);
+                d1 += dot4(gv, acc[k]);
+                if (a.self) d2 += dot4(gv, ld4(sp + c0));
+            }
+        }
+        d1 = group_sum<LPR>(d1); d2 = group_sum<LPR>(d2);
+        if (writer && l == 0) {
+            if (a.aux1) a.aux1[slot] = invd * d1;
+            if (a.aux2) a.aux2[slot] = invd * d2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// main kernel: one wave per item = (row slot, nnz range [begin,end), partial slot or -1)
+// ---------------------------------------------------------------------------------------------
+template <int LPR, int NV, typename TIn, typename TOut, int EPI>
+__global__ void __launch_bounds__(kBlock) agg_main(const KArgs a) {
+    constexpr int G = 64 / LPR;                   // non-zeros of one row processed side by side
+    const int lane = threadIdx.x & 63;
+    const long item = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (item >= a.n_items) return;                // whole wave exits together
+    const int4 it = a.items[item];
+    const int slot = it.x, begin = it.y, end = it.z, pslot = it.w;
+    const int sub = lane / LPR, l = lane % LPR;
+    const TIn* __restrict__ src = reinterpret_cast<const TIn*>(a.src);
+
+    float4 acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // coalesced fetch of 64 (col, weight) pairs; alpha / inv_deg folded into the weight once per edge
+    auto fetch = [&](int base, int& c, float& w) {
+        const int n = min(64, end - base);
+        const int idx = base + min(lane, n - 1);
+        c = a.col[idx];
+        float ww = a.val[idx];
+        if (a.cs1) ww *= a.cs1[c];
+        if (a.cs2) ww *= a.cs2[c];
+        w = lane < n ? ww : 0.f;
+    };
+
+    int c_cur = 0; float w_cur = 0.f;
+    if (begin < end) fetch(begin, c_cur, w_cur);
+    for (int base = begin; base < end; base += 64) {
+        int c_nxt = 0; float w_nxt = 0.f;
+        if (base + 64 < end) fetch(base + 64, c_nxt, w_nxt);          // software prefetch of the next tile
+        const int n = min(64, end - base);
+        const int steps = (n + G - 1) / G;
+#pragma unroll 4
+        for (int j = 0; j < steps; ++j) {
+            int c; float w;
+            if constexpr (G == 1) {
+                c = __builtin_amdgcn_readlane(c_cur, j);
+                w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w_cur), j));
+            } else {
+                c = __shfl(c_cur, j * G + sub, 64);
+                w = __shfl(w_cur, j * G + sub, 64);
+            }
+            const TIn* p = src + (size_t)c * a.ld_src;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int c0 = (k * LPR + l) * 4;
+                if (c0 < a.D) fma4(acc[k], w, ld4(p + c0));
+            }
+        }
+        c_cur = c_nxt; w_cur = w_nxt;
+    }
+    // fold the G lane groups (each holds a partial sum over its share of the non-zeros)
+    if constexpr (G > 1) {
+#pragma unroll
+        for (int off = LPR; off < 64; off <<= 1) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                acc[k].x += __shfl_xor(acc[k].x, off, 64); acc[k].y += __shfl_xor(acc[k].y, off, 64);
+                acc[k].z += __shfl_xor(acc[k].z, off, 64); acc[k].w += __shfl_xor(acc[k].w, off, 64);
+            }
+        }
+    }
+    const bool writer = (sub == 0);
+    if (pslot >= 0) {
+        float* pp = a.partials + (size_t)pslot * a.D;
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int c0 = (k * LPR + l) * 4;
+            if (writer && c0 < a.D) st4(pp + c0, acc[k]);
+        }
+    } else {
+        epilogue<LPR, NV, TIn, TOut, EPI>(a, acc, slot, l, writer);
+    }
+}
+
+// finalize: one wave per long row; folds its partial sums in slot order, then the same epilogue
+template <int LPR, int NV, typename TIn, typename TOut, int EPI>
+__global__ void __launch_bounds__(kBlock) agg_finalize(const KArgs a) {
+    const int lane = threadIdx.x & 63;
+    const long idx = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (idx >= a.n_long) return;
+    const int4 lr = a.long_rows[idx];
+    const int sub = lane / LPR, l = lane % LPR;
+    float4 acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (sub == 0) {
+        for (int p = 0; p < lr.z; ++p) {
+            const float* pp = a.partials + (size_t)(lr.y + p) * a.D;
+#pragma unroll
+            for (int k = 0; k < NV; ++k) {
+                const int c0 = (k * LPR + l) * 4;
+                if (c0 < a.D) { const float4 v = ld4(pp + c0); acc[k].x += v.x; acc[k].y += v.y; acc[k].z += v.z; acc[k].w += v.w; }
+            }
+        }
+    }
+    epilogue<LPR, NV, TIn, TOut, EPI>(a, acc, lr.x, l, sub == 0);
+}
+
+// K4: normalize_weight - one wave per row
+__global__ void __launch_bounds__(kBlock) normalize_rows(const int* __restrict__ rowptr, const float* __restrict__ vin,
+                                                         float* __restrict__ vout, float* __restrict__ inv_deg, long n_rows) {
+    const int lane = threadIdx.x & 63;
+    const long r = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (r >= n_rows) return;
+    const int b = rowptr[r], e = rowptr[r + 1];
+    float s = 0.f;
+    for (int j = b + lane; j < e; j += 64) s += vin[j];
+    s = group_sum<64>(s);
+    const float deg = (float)(e - b);
+    for (int j = b + lane; j < e; j += 64) vout[j] = deg * vin[j] / s;     // (deg*w)/sum, preprocess_internal.py:23
+    if (inv_deg && lane == 0) inv_deg[r] = 1.0f / (deg + 1.0f);
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side dispatch
+// ---------------------------------------------------------------------------------------------
+template <int LPR, int NV, typename TIn, typename TOut, int EPI>
+int launch(const KArgs& a, hipStream_t st) {
+    if (a.n_items > 0) {
+        const long nb = (a.n_items + kWavesPerBlock - 1) / kWavesPerBlock;
+        hipLaunchKernelGGL((agg_main<LPR, NV, TIn, TOut, EPI>), dim3((unsigned)nb), dim3(kBlock), 0, st, a);
+    }
+    if (a.n_long > 0) {
+        const long nb = (a.n_long + kWavesPerBlock - 1) / kWavesPerBlock;
+        hipLaunchKernelGGL((agg_finalize<LPR, NV, TIn, TOut, EPI>), dim3((unsigned)nb), dim3(kBlock), 0, st, a);
+    }
+    return hipGetLastError() == hipSuccess ? WGNN_OK : WGNN_ERR_LAUNCH;
+}
+
+template <typename TIn, typename TOut, int EPI>
+int dispatch_width(const KArgs& a, hipStream_t st) {
+    const int q = a.D / 4;
+    if (q <= 8)   return launch<8, 1, TIn, TOut, EPI>(a, st);
+    if (q <= 16)  return launch<16, 1, TIn, TOut, EPI>(a, st);
+    if (q <= 32)  return launch<32, 1, TIn, TOut, EPI>(a, st);
+    if (q <= 64)  return launch<64, 1, TIn, TOut, EPI>(a, st);
+    if (q <= 128) return launch<64, 2, TIn, TOut, EPI>(a, st);
+    if (q <= 256) return launch<64, 4, TIn, TOut, EPI>(a, st);
+    return WGNN_ERR_UNSUPPORTED;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7u) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+int wgnn_version(void) { return WGNN_VERSION; }
+
+const char* wgnn_last_error_string(int code) {
+    switch (code) {
+        case WGNN_OK: return "ok";
+        case WGNN_ERR_BAD_ARG: return "bad argument (null pointer, negative size or bad enum)";
+        case WGNN_ERR_ALIGNMENT: return "D / leading dimension not a multiple of 4 or pointer not 16-byte aligned";
+        case WGNN_ERR_UNSUPPORTED: return "unsupported dtype or feature width (D <= 1024 required)";
+        case WGNN_ERR_WORKSPACE: return "workspace (partials) too small or missing";
+        case WGNN_ERR_LAUNCH: return "HIP launch failed";
+        case WGNN_ERR_PLAN: return "plan malformed";
+        default: return "unknown error";
+    }
+}
+
+int wgnn_plan_build_host(const int32_t* rowptr, const int32_t* row_ids, int64_t n_rows, int32_t chunk,
+                         int32_t* items, int32_t* long_rows, int64_t* n_items, int64_t* n_long, int64_t* n_partials) {
+    if (!rowptr || n_rows < 0 || chunk <= 0 || !n_items || !n_long || !n_partials) return WGNN_ERR_BAD_ARG;
+    int64_t ni = 0, nl = 0, np = 0;
+    for (int64_t i = 0; i < n_rows; ++i) {
+        const int64_t r = row_ids ? row_ids[i] : i;
+        const int32_t b = rowptr[r], e = rowptr[r + 1];
+        if (e < b) return WGNN_ERR_PLAN;
+        const int32_t nnz = e - b;
+        if (nnz <= chunk) {
+            if (items) { int32_t* it = items + 4 * ni; it[0] = (int32_t)i; it[1] = b; it[2] = e; it[3] = -1; }
+            ++ni;
+        } else {
+            const int32_t nc = (nnz + chunk - 1) / chunk;
+            if (long_rows) { int32_t* lr = long_rows + 4 * nl; lr[0] = (int32_t)i; lr[1] = (int32_t)np; lr[2] = nc; lr[3] = 0; }
+            for (int32_t c = 0; c < nc; ++c) {
+                if (items) {
+                    int32_t* it = items + 4 * ni;
+                    it[0] = (int32_t)i; it[1] = b + c * chunk; it[2] = (b + (c + 1) * chunk < e) ? b + (c + 1) * chunk : e;
+                    it[3] = (int32_t)(np + c);
+                }
+                ++ni;
+            }
+            np += nc; ++nl;
+        }
+    }
+    *n_items = ni; *n_long = nl; *n_partials = np;
+    return WGNN_OK;
+}
+
+static int check_common(int32_t D, int64_t n, const void* items, int64_t n_items, const void* long_rows,
+                        int64_t n_long, const float* partials, int64_t n_partials) {
+    if (D <= 0 || n < 0 || n_items < 0 || n_long < 0) return WGNN_ERR_BAD_ARG;
+    if (D % 4) return WGNN_ERR_ALIGNMENT;
+    if (D > 1024) return WGNN_ERR_UNSUPPORTED;
+    if (n_items > 0 && !items) return WGNN_ERR_BAD_ARG;
+    if (n_long > 0 && (!long_rows || !partials || n_partials <= 0)) return WGNN_ERR_WORKSPACE;
+    return WGNN_OK;
+}
+
+int wgnn_agg_fwd(const int32_t* rowptr, const int32_t* col, const float* val,
+                 const float* alpha, int alpha_mode, int32_t self_idx,
+                 const void* h_src, int64_t ld_src, const void* h_self, int64_t ld_self,
+                 const int32_t* row_ids, const float* inv_deg, const float* bias,
+                 void* out, int64_t ld_out, int64_t n_out, int32_t D, int dtype_in, int dtype_out, uint32_t flags,
+                 const int32_t* items, int64_t n_items, const int32_t* long_rows, int64_t n_long,
+                 float* partials, int64_t n_partials, void* stream) {
+    int rc = check_common(D, n_out, items, n_items, long_rows, n_long, partials, n_partials);
+    if (rc) return rc;
+    if (!rowptr || !col || !val || !h_src || !out) return WGNN_ERR_BAD_ARG;
+    if (alpha_mode < WGNN_SRC_IS_GENE || alpha_mode > WGNN_NO_ALPHA) return WGNN_ERR_BAD_ARG;
+    if (alpha_mode != WGNN_NO_ALPHA && !alpha) return WGNN_ERR_BAD_ARG;
+    if (ld_src % 4 || ld_out % 4 || (h_self && ld_self % 4)) return WGNN_ERR_ALIGNMENT;
+    const bool in16 = dtype_in == WGNN_F16, out16 = dtype_out == WGNN_F16;
+    if ((dtype_in != WGNN_F32 && !in16) || (dtype_out != WGNN_F32 && !out16)) return WGNN_ERR_UNSUPPORTED;
+    if (!(in16 ? aligned8(h_src) : aligned16(h_src)) || !(out16 ? aligned8(out) : aligned16(out)) ||
+        (h_self && !(in16 ? aligned8(h_self) : aligned16(h_self))) || (bias && !aligned16(bias)))
+        return WGNN_ERR_ALIGNMENT;
+    if (n_out == 0) return WGNN_OK;
+    KArgs a{};
+    a.rowptr = rowptr; a.col = col; a.val = val;
+    a.cs1 = (alpha_mode == WGNN_SRC_IS_GENE) ? alpha : nullptr; a.cs2 = nullptr;
+    a.src = h_src; a.ld_src = ld_src; a.alpha = alpha; a.mode = alpha_mode; a.self_idx = self_idx;
+    a.self = h_self; a.ld_self = ld_self; a.row_ids = row_ids; a.inv_deg = inv_deg; a.bias = bias;
+    a.out = out; a.ld_out = ld_out; a.D = D; a.flags = flags;
+    a.items = reinterpret_cast<const int4*>(items); a.n_items = n_items;
+    a.long_rows = reinterpret_cast<const int4*>(long_rows); a.n_long = n_long; a.partials = partials;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!in16 && !out16) return dispatch_width<float, float, EPI_FWD>(a, st);
+    if (in16 && !out16)  return dispatch_width<__half, float, EPI_FWD>(a, st);
+    if (in16 && out16)   return dispatch_width<__half, __half, EPI_FWD>(a, st);
+    return WGNN_ERR_UNSUPPORTED;
+}
+
+int wgnn_agg_bwd_src(const int32_t* t_rowptr, const int32_t* t_col, const float* t_val,
+                     const float* alpha, int alpha_mode, const float* inv_deg_dst,
+                     const float* g, int64_t ld_g, const float* h_src, int64_t ld_src,
+                     float* dh_src, int64_t ld_dh, float* dalpha, int accumulate,
+                     int64_t n_src, int32_t D,
+                     const int32_t* items, int64_t n_items, const int32_t* long_rows, int64_t n_long,
+                     float* partials, int64_t n_partials, void* stream) {
+    int rc = check_common(D, n_src, items, n_items, long_rows, n_long, partials, n_partials);
+    if (rc) return rc;
+    if (!t_rowptr || !t_col || !t_val || !g || !dh_src) return WGNN_ERR_BAD_ARG;
+    if (alpha_mode < WGNN_SRC_IS_GENE || alpha_mode > WGNN_NO_ALPHA) return WGNN_ERR_BAD_ARG;
+    if (alpha_mode != WGNN_NO_ALPHA && !alpha) return WGNN_ERR_BAD_ARG;
+    if (ld_g % 4 || ld_dh % 4 || (h_src && ld_src % 4)) return WGNN_ERR_ALIGNMENT;
+    if (!aligned16(g) || !aligned16(dh_src) || (h_src && !aligned16(h_src))) return WGNN_ERR_ALIGNMENT;
+    if (n_src == 0) return WGNN_OK;
+    KArgs a{};
+    a.rowptr = t_rowptr; a.col = t_col; a.val = t_val;
+    a.cs1 = inv_deg_dst; a.cs2 = (alpha_mode == WGNN_DST_IS_GENE) ? alpha : nullptr;
+    a.src = g; a.ld_src = ld_g; a.alpha = alpha; a.mode = alpha_mode;
+    a.self = h_src; a.ld_self = ld_src; a.out = dh_src; a.ld_out = ld_dh; a.aux1 = dalpha;
+    a.D = D; a.flags = WGNN_FLAG_NO_MEAN; a.accumulate = accumulate;
+    a.items = reinterpret_cast<const int4*>(items); a.n_items = n_items;
+    a.long_rows = reinterpret_cast<const int4*>(long_rows); a.n_long = n_long; a.partials = partials;
+    return dispatch_width<float, float, EPI_BWD_SRC>(a, static_cast<hipStream_t>(stream));
+}
+
+int wgnn_agg_bwd_alpha(const int32_t* rowptr, const int32_t* col, const float* val,
+                       const float* inv_deg, const int32_t* row_ids,
+                       const float* g, int64_t ld_g, const float* h_src, int64_t ld_src,
+                       const float* h_self, int64_t ld_self, float* dalpha_row, float* dself_row,
+                       int64_t n_out, int32_t D, uint32_t flags,
+                       const int32_t* items, int64_t n_items, const int32_t* long_rows, int64_t n_long,
+                       float* partials, int64_t n_partials, void* stream) {
+    int rc = check_common(D, n_out, items, n_items, long_rows, n_long, partials, n_partials);
+    if (rc) return rc;
+    if (!rowptr || !col || !val || !g || !h_src) return WGNN_ERR_BAD_ARG;
+    if (ld_g % 4 || ld_src % 4 || (h_self && ld_self % 4)) return WGNN_ERR_ALIGNMENT;
+    if (!aligned16(g) || !aligned16(h_src) || (h_self && !aligned16(h_self))) return WGNN_ERR_ALIGNMENT;
+    if (n_out == 0) return WGNN_OK;
+    KArgs a{};
+    a.rowptr = rowptr; a.col = col; a.val = val;
+    a.src = h_src; a.ld_src = ld_src; a.mode = WGNN_NO_ALPHA;
+    a.self = h_self; a.ld_self = ld_self; a.row_ids = row_ids; a.inv_deg = inv_deg;
+    a.g = g; a.ld_g = ld_g; a.aux1 = dalpha_row; a.aux2 = dself_row;
+    a.D = D; a.flags = flags & WGNN_FLAG_SELF_COMPACT;
+    a.items = reinterpret_cast<const int4*>(items); a.n_items = n_items;
+    a.long_rows = reinterpret_cast<const int4*>(long_rows); a.n_long = n_long; a.partials = partials;
+    return dispatch_width<float, float, EPI_BWD_ALPHA>(a, static_cast<hipStream_t>(stream));
+}
+
+int wgnn_normalize_rows(const int32_t* rowptr, const float* val_in, float* val_out, float* inv_deg,
+                        int64_t n_rows, void* stream) {
+    if (!rowptr || !val_in || !val_out || n_rows < 0) return WGNN_ERR_BAD_ARG;
+    if (n_rows == 0) return WGNN_OK;
+    const long nb = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
+    hipLaunchKernelGGL(normalize_rows, dim3((unsigned)nb), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       rowptr, val_in, val_out, inv_deg, (long)n_rows);
+    return hipGetLastError() == hipSuccess ? WGNN_OK : WGNN_ERR_LAUNCH;
+}
+
+}  // extern "C"

@@ -1,0 +1,116 @@
+"""Cell-axis sharding of the hot path across the GPUs of one node.
+
+The reference is single-process (no collective anywhere in its tree); this is new design.
+One process per GPU (``torch.distributed``, backend ``nccl`` = RCCL over xGMI on ROCm,
+``gloo`` in CPU tests).  Rank p owns a contiguous range of cells:
+
+* cells<-genes passes are row-independent: local CSR rows, replicated gene table -> no communication;
+* the genes<-cells pass has ONE real exchange: every rank reduces its own cells into a partial
+  ``[G, H]`` sum (NO_ALPHA / NO_MEAN / no self), the partials are all-reduced (20.5 MB at G=20k,
+  H=256 - a single bucket), then alpha, the gene self-loop, 1/deg, bias and ReLU are applied
+  redundantly on every rank;
+* gene-side normalisation needs global per-gene degree and weight sum: two ``[G]`` all-reduces at
+  graph-build time;
+* inference outputs are concatenated with one all-gather of ``[C/N, n_classes]`` logits;
+* training: CrossEntropyLoss(reduction='sum') (train.py:36) makes summed per-rank gradients equal
+  the single-GPU gradient, so parameter grads are all-reduced with SUM (no rescale).
+
+The local arithmetic is injected (``local_ops``) so the orchestration is testable on CPU with
+gloo; the product binds it to the HIP operators.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(num_cells: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous, balanced (sizes differ by <= 1) cell range of ``rank``."""
+    base, rem = divmod(num_cells, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def world() -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
+    if world()[1] > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t
+
+
+def normalise_gene_side(local_deg: torch.Tensor, local_sum: torch.Tensor, local_val_locally_normalised: torch.Tensor,
+                        row_of_nnz: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Turn per-shard normalised gene<-cell weights into globally normalised ones.
+
+    Locally ``w = deg_loc * x / sum_loc`` (K4 on the shard); globally the reference needs
+    ``deg_glob * x / sum_glob`` (normalize_weight over ALL in-edges of the gene,
+    preprocess_internal.py:17-23), i.e. a per-gene factor ``(deg_glob/deg_loc) * (sum_loc/sum_glob)``.
+    Returns (values, inv_deg_global).
+    """
+    g_deg = all_reduce_sum_(local_deg.clone().float())
+    g_sum = all_reduce_sum_(local_sum.clone().double())
+    fac = torch.where(local_deg > 0, (g_deg / local_deg.clamp(min=1).float()) *
+                      (local_sum.double() / g_sum.clamp(min=1e-30)).float(), torch.zeros_like(g_deg))
+    return local_val_locally_normalised * fac[row_of_nnz.long()], 1.0 / (g_deg + 1.0)
+
+
+@dataclass
+class LocalOps:
+    """Local arithmetic of one shard (bound to the HIP operators in production)."""
+    cells_layer: Callable      # (p_g, p_c_local, bias, relu)              -> h_c_local'
+    genes_partial: Callable    # (p_c_local)                               -> partial [G, H] (plain weighted sum)
+    genes_finish: Callable     # (partial_sum_global, p_g, bias, relu)     -> h_g'
+
+
+def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local: torch.Tensor, ops: LocalOps,
+                    n_layers: int, gather_logits: bool = True) -> torch.Tensor:
+    """Layer-wise forward over a cell shard.  ``weights`` = list of (W_i, b_i) + (W_out, b_out) last."""
+    h_g, h_c = feats_g, feats_c_local
+    for i in range(n_layers):
+        W, b = weights[i]
+        last = i == n_layers - 1
+        p_g = torch.nn.functional.linear(h_g, W)
+        p_c = torch.nn.functional.linear(h_c, W)
+        new_c = ops.cells_layer(p_g, p_c, b, True)
+        if not last:
+            part = ops.genes_partial(p_c)
+            all_reduce_sum_(part)                       # the ONE data-path collective (X2)
+            h_g = ops.genes_finish(part, p_g, b, True)
+        h_c = new_c
+    Wo, bo = weights[n_layers]
+    logits = torch.nn.functional.linear(h_c, Wo, bo)
+    rank, ws = world()
+    if gather_logits and ws > 1:
+        sizes = [torch.zeros(1, dtype=torch.long, device=logits.device) for _ in range(ws)]
+        dist.all_gather(sizes, torch.tensor([logits.shape[0]], dtype=torch.long, device=logits.device))
+        mx = int(max(s.item() for s in sizes))
+        pad = torch.zeros(mx, logits.shape[1], dtype=logits.dtype, device=logits.device)
+        pad[: logits.shape[0]] = logits
+        outs = [torch.empty_like(pad) for _ in range(ws)]
+        dist.all_gather(outs, pad)                      # X3: inference concat
+        logits = torch.cat([o[: int(s.item())] for o, s in zip(outs, sizes)])
+    return logits
+
+
+def all_reduce_grads(params) -> None:
+    """X1: SUM all-reduce of parameter gradients in one flat bucket (~0.8 MB at cfg3)."""
+    if world()[1] == 1:
+        return
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off:off + n].view_as(g))
+        off += n

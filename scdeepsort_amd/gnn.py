@@ -1,0 +1,137 @@
+"""``GNN`` - drop-in counterpart of the reference's ``models/gnn.py:28-68``.
+
+Same constructor signature, same parameter names / shapes (so released
+``{'model': state_dict}`` checkpoints load, train.py:117-123 / predict.py:56-59):
+
+    layers.{i}.fc_neigh.weight [H, D_in | H]   layers.{i}.fc_neigh.bias [H]
+    alpha [gene_num + 2, 1]                    linear.weight [n_cls, H]   linear.bias [n_cls]
+
+What changes is the operand of ``forward``: instead of a DGL ``NodeFlow`` built per
+seed batch (train.py:71-81) it takes the HBM-resident :class:`CellGeneGraph` and
+evaluates the layers over the whole graph at once: each seed's
+logits depend only on its full L-hop in-neighbourhood, which the reference's
+sampler takes in full (``expand_factor`` = all nodes, train.py:37-38), so the
+result is identical per seed while the per-batch recomputation of the closure
+disappears.  ``seeds`` selects / orders the output rows exactly like
+``nf.layer_parent_nid(-1)`` (train.py:81, predict.py:75-76).
+
+Per layer (gnn.py:60-65, 18-25) with ``Z = mean-aggregate`` and ``NodeUpdate = relu(W Z + b)``:
+the aggregation is linear, so when ``H <= D_in`` the projection is applied first
+(``P = h W^T`` once for all nodes, then ``relu(agg(P) + b)`` fused in the kernel
+epilogue), which narrows every gathered row from D_in to H floats.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ._lib import DST_IS_GENE, SRC_IS_GENE
+from .graph import CellGeneGraph
+from .ops import weighted_mean_aggregate
+
+
+class NodeUpdate(nn.Module):
+    """Parameter holder with the reference's names (gnn.py:10-16); applied by GNN.forward."""
+
+    def __init__(self, in_feats, out_feats, activation=None, norm=None):
+        super().__init__()
+        self.fc_neigh = nn.Linear(in_features=in_feats, out_features=out_feats)
+        self.activation = activation
+        self.norm = norm
+        nn.init.xavier_uniform_(self.fc_neigh.weight, gain=nn.init.calculate_gain('relu'))
+
+
+def _is_relu(fn) -> bool:
+    return fn in (F.relu, torch.relu) or isinstance(fn, nn.ReLU)
+
+
+class GNN(nn.Module):
+    def __init__(self, in_feats, n_hidden, n_classes, n_layers, gene_num, activation=None, norm=None, dropout=0.0):
+        super().__init__()
+        self.n_layers = n_layers
+        self.gene_num = gene_num
+        self.dropout = nn.Dropout(p=dropout) if dropout != 0 else None
+        self.layers = nn.ModuleList()
+        self.layers.append(NodeUpdate(in_feats, n_hidden, activation=activation, norm=norm))
+        for _ in range(n_layers - 1):
+            self.layers.append(NodeUpdate(n_hidden, n_hidden, activation=activation, norm=norm))
+        # [gene_num] is alpha of gene-gene (self-loop), [gene_num+1] of the cell self-loop (gnn.py:42-43)
+        self.alpha = nn.Parameter(torch.ones(gene_num + 2, 1, dtype=torch.float32))
+        self.linear = nn.Linear(n_hidden, n_classes)
+        nn.init.xavier_uniform_(self.linear.weight, gain=nn.init.calculate_gain('relu'))
+        self.order = "auto"          # "auto" | "project_first" | "aggregate_first"
+
+    # -- one NodeFlow block, both node types ------------------------------------------------------
+    def _layer(self, g: CellGeneGraph, layer: NodeUpdate, h_g: torch.Tensor, h_c: torch.Tensor,
+               want_genes: bool, cell_rows: Optional[torch.Tensor]):
+        G = self.gene_num
+        W, b = layer.fc_neigh.weight, layer.fc_neigh.bias
+        act = layer.activation
+        fuse_relu = _is_relu(act)
+        project_first = self.order == "project_first" or (self.order == "auto" and W.shape[0] <= W.shape[1])
+        if self.dropout is not None:                       # node rows, before the gather (gnn.py:62-64)
+            h_g, h_c = self.dropout(h_g), self.dropout(h_c)
+
+        def finish(x):
+            if act is not None and not fuse_relu:
+                x = act(x)
+            if layer.norm is not None:
+                x = layer.norm(x)
+            return x
+
+        compact = cell_rows is not None
+        if project_first:
+            p_g = F.linear(h_g, W)
+            need_all_cells = want_genes or not compact
+            p_c_all = F.linear(h_c, W) if need_all_cells else None
+            p_c_self = p_c_all if not compact else (p_c_all[cell_rows.long()] if p_c_all is not None
+                                                    else F.linear(h_c[cell_rows.long()], W))
+            out_c = weighted_mean_aggregate(g.cg, self.alpha, SRC_IS_GENE, G + 1, p_g, p_c_self, bias=b,
+                                            relu=fuse_relu, row_ids=cell_rows, self_compact=compact)
+            out_g = None
+            if want_genes:
+                out_g = weighted_mean_aggregate(g.gc, self.alpha, DST_IS_GENE, G, p_c_all, p_g, bias=b, relu=fuse_relu)
+            return (finish(out_g) if out_g is not None else None), finish(out_c)
+        # aggregate first (the reference's literal order: neigh -> fc_neigh -> activation)
+        hc_self = h_c if not compact else h_c[cell_rows.long()]
+        z_c = weighted_mean_aggregate(g.cg, self.alpha, SRC_IS_GENE, G + 1, h_g, hc_self, row_ids=cell_rows,
+                                      self_compact=compact)
+        out_c = F.linear(z_c, W, b)
+        out_c = F.relu(out_c) if fuse_relu else out_c
+        out_g = None
+        if want_genes:
+            z_g = weighted_mean_aggregate(g.gc, self.alpha, DST_IS_GENE, G, h_c, h_g)
+            out_g = F.linear(z_g, W, b)
+            out_g = finish(F.relu(out_g) if fuse_relu else out_g)
+        return out_g, finish(out_c)
+
+    def embed(self, g: CellGeneGraph, features: torch.Tensor, seeds: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Cell embeddings = ``nf.layers[-1].data['activation']`` (gnn.py:66) for ``seeds`` (node ids >= G)."""
+        G = self.gene_num
+        if isinstance(features, (tuple, list)):            # (gene rows, cell rows) kept as separate tensors
+            h_g, h_c = features
+            if h_g.shape[0] != G or h_c.shape[0] != g.num_cells:
+                raise ValueError("features tuple must be ([G, D], [C, D])")
+        else:
+            if features.shape[0] != g.num_nodes:
+                raise ValueError(f"features must have {g.num_nodes} rows (genes then cells, preprocess_internal.py:202)")
+            h_g, h_c = features[:G], features[G:]
+        cell_rows = None
+        if seeds is not None:
+            cell_rows = (seeds.to(g.device) - G).to(torch.int32)
+        for i, layer in enumerate(self.layers):
+            last = i == self.n_layers - 1
+            h_g, h_c = self._layer(g, layer, h_g, h_c, want_genes=not last, cell_rows=cell_rows if last else None)
+        return h_c
+
+    def forward(self, g: CellGeneGraph, features: Optional[torch.Tensor] = None,
+                seeds: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Logits ``[len(seeds), n_classes]`` (all cells in order when ``seeds`` is None); no softmax (gnn.py:66-68)."""
+        if features is None:
+            features = getattr(g, "features", None)
+            if features is None:
+                raise ValueError("pass features or set graph.features")
+        return self.linear(self.embed(g, features, seeds))

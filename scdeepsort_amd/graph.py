@@ -1,0 +1,226 @@
+"""HBM-resident operand of the hot path: the bipartite cell-gene graph.
+
+Reference counterpart: the DGLGraph assembled in
+``utils/preprocess_internal.py:107-110,160-173,210-215`` (training graph) and
+``utils/preprocess.py:102-134,184-187,212-221`` (predict graph): genes are nodes
+``[0,G)``, cells follow; every expression value > threshold is a gene->cell edge
+and (for support/training cells) a cell->gene edge; in-edge weights are
+normalised per destination (``normalize_weight``, preprocess_internal.py:15-23)
+and THEN a unit self-loop is added to every node.
+
+Layout here (one copy per GPU, all device tensors):
+
+* ``cg``  destination-major CSR of cells<-genes  (rows = cells,  col = gene id)
+* ``gc``  destination-major CSR of genes<-cells  (rows = genes,  col = cell id)
+* per direction: ``inv_deg = 1/(in_degree+1)`` (self-loop counted, implicit),
+  an execution *plan* (row chunks, see ``wgnn_plan_build_host``) and - built
+  lazily for training - the transposed structure with the same normalised
+  values re-ordered (``normalize_weight`` is per destination, so the two
+  directions carry different values and the backward of one direction is NOT
+  the forward CSR of the other).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+DEFAULT_CHUNK = 2048
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _stream(device: torch.device) -> Optional[int]:
+    return torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else None
+
+
+@dataclass
+class Plan:
+    """Row-chunk work list for one CSR (device copies + counts)."""
+    items: torch.Tensor          # int32 [n_items, 4]  {row_slot, begin, end, partial_slot|-1}
+    long_rows: torch.Tensor      # int32 [n_long, 4]   {row_slot, first_partial, n_partials, 0}
+    n_partials: int
+    chunk: int
+
+    @property
+    def n_items(self) -> int:
+        return self.items.shape[0]
+
+    @property
+    def n_long(self) -> int:
+        return self.long_rows.shape[0]
+
+
+def build_plan(rowptr_host: np.ndarray, chunk: int = DEFAULT_CHUNK, row_ids_host: Optional[np.ndarray] = None,
+               device: torch.device | str = "cpu") -> Plan:
+    """Host-side plan construction through the C ABI (``wgnn_plan_build_host``)."""
+    lib = _lib.lib()
+    rowptr_host = np.ascontiguousarray(rowptr_host, dtype=np.int32)
+    n_rows = len(row_ids_host) if row_ids_host is not None else len(rowptr_host) - 1
+    rid = None
+    if row_ids_host is not None:
+        rid = np.ascontiguousarray(row_ids_host, dtype=np.int32)
+    ni, nl, npart = C.c_int64(), C.c_int64(), C.c_int64()
+    rid_p = rid.ctypes.data if rid is not None else None
+    _lib.check(lib.wgnn_plan_build_host(rowptr_host.ctypes.data, rid_p, n_rows, chunk, None, None,
+                                        C.addressof(ni), C.addressof(nl), C.addressof(npart)), "wgnn_plan_build_host")
+    items = np.empty((ni.value, 4), dtype=np.int32)
+    longs = np.empty((nl.value, 4), dtype=np.int32)
+    _lib.check(lib.wgnn_plan_build_host(rowptr_host.ctypes.data, rid_p, n_rows, chunk,
+                                        items.ctypes.data, longs.ctypes.data,
+                                        C.addressof(ni), C.addressof(nl), C.addressof(npart)), "wgnn_plan_build_host")
+    return Plan(torch.from_numpy(items).to(device), torch.from_numpy(longs).to(device), int(npart.value), chunk)
+
+
+@dataclass
+class AggCsr:
+    """One aggregation direction: destination-major CSR + normalised values + plan."""
+    rowptr: torch.Tensor                 # int32 [R+1]
+    col: torch.Tensor                    # int32 [nnz]
+    val: torch.Tensor                    # float32 [nnz]   normalised weights
+    inv_deg: torch.Tensor                # float32 [R]     1/(deg+1)
+    n_rows: int
+    n_cols: int
+    plan: Plan
+    rowptr_host: np.ndarray
+    _t: Optional["AggCsr"] = field(default=None, repr=False)
+
+    @property
+    def nnz(self) -> int:
+        return self.col.shape[0]
+
+    @property
+    def device(self) -> torch.device:
+        return self.col.device
+
+    def transposed(self) -> "AggCsr":
+        """Source-major copy: row s lists the destinations it feeds, values re-ordered (for K2)."""
+        if self._t is None:
+            dev = self.device
+            counts = torch.bincount(self.col.long(), minlength=self.n_cols)
+            t_rowptr = torch.zeros(self.n_cols + 1, dtype=torch.int64, device=dev)
+            torch.cumsum(counts, 0, out=t_rowptr[1:])
+            rows = torch.repeat_interleave(torch.arange(self.n_rows, device=dev, dtype=torch.int32),
+                                           (self.rowptr[1:] - self.rowptr[:-1]).long())
+            order = torch.sort(self.col.long(), stable=True).indices
+            t_col = rows[order].contiguous()
+            t_val = self.val[order].contiguous()
+            t_rowptr32 = t_rowptr.to(torch.int32)
+            host = t_rowptr32.cpu().numpy()
+            self._t = AggCsr(t_rowptr32, t_col, t_val, torch.empty(0, device=dev), self.n_cols, self.n_rows,
+                             build_plan(host, self.plan.chunk, device=dev), host)
+        return self._t
+
+    def subplan(self, row_ids: torch.Tensor) -> Tuple[torch.Tensor, Plan]:
+        """Plan restricted to a seed subset (one NodeFlow batch, train.py:71-81).  Not cached: the id
+        tensor's storage may be recycled with other contents between calls."""
+        ids32 = row_ids.to(torch.int32).contiguous()
+        plan = build_plan(self.rowptr_host, self.plan.chunk, ids32.cpu().numpy(), device=self.device)
+        return ids32.to(self.device), plan
+
+
+def _normalize_on_device(rowptr: torch.Tensor, raw: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """K4 (``wgnn_normalize_rows``): w <- deg*w/sum(w) per destination, inv_deg = 1/(deg+1)."""
+    if raw.device.type != "cuda":
+        raise _lib.WgnnError("graph normalisation runs on the GPU (wgnn_normalize_rows); no CPU fallback")
+    n_rows = rowptr.shape[0] - 1
+    out = torch.empty_like(raw)
+    inv_deg = torch.empty(n_rows, dtype=torch.float32, device=raw.device)
+    _lib.check(_lib.lib().wgnn_normalize_rows(_ptr(rowptr), _ptr(raw), _ptr(out), _ptr(inv_deg), n_rows,
+                                              _stream(raw.device)), "wgnn_normalize_rows")
+    return out, inv_deg
+
+
+def _make_csr(rowptr_host: np.ndarray, col_host: np.ndarray, raw_host: np.ndarray, n_rows: int, n_cols: int,
+              device: torch.device, chunk: int) -> AggCsr:
+    if rowptr_host[-1] >= 2 ** 31:
+        raise ValueError("nnz >= 2^31: shard the cell axis (CellGeneGraph.shard)")
+    rowptr = torch.from_numpy(np.ascontiguousarray(rowptr_host, dtype=np.int32)).to(device)
+    col = torch.from_numpy(np.ascontiguousarray(col_host, dtype=np.int32)).to(device)
+    raw = torch.from_numpy(np.ascontiguousarray(raw_host, dtype=np.float32)).to(device)
+    val, inv_deg = _normalize_on_device(rowptr, raw)
+    host = np.ascontiguousarray(rowptr_host, dtype=np.int32)
+    return AggCsr(rowptr, col, val, inv_deg, n_rows, n_cols, build_plan(host, chunk, device=device), host)
+
+
+@dataclass
+class CellGeneGraph:
+    num_genes: int
+    num_cells: int
+    cg: AggCsr          # cells <- genes
+    gc: AggCsr          # genes <- cells   (support cells only; test cells feed nothing back, preprocess.py:184-187)
+    cell_offset: int = 0     # first global cell id held by this shard (multi-GPU)
+    num_cells_global: int = 0
+
+    @property
+    def device(self) -> torch.device:
+        return self.cg.device
+
+    @property
+    def num_nodes(self) -> int:
+        return self.num_genes + self.num_cells
+
+    @staticmethod
+    def from_expression(expr, support_mask: Optional[np.ndarray] = None, device: torch.device | str = "cuda",
+                        chunk: int = DEFAULT_CHUNK) -> "CellGeneGraph":
+        """Build from a scipy (cells x genes) matrix of raw expression values (entries > threshold only).
+
+        Mirrors the reference build order: both edge directions from the same raw value
+        (preprocess_internal.py:170-173), per-destination normalisation (:211), implicit self-loops (:213).
+        """
+        import scipy.sparse as sp
+        device = torch.device(device)
+        x = sp.csr_matrix(expr).astype(np.float32)
+        x.sort_indices()
+        C_, G_ = x.shape
+        if support_mask is None:
+            xs = x
+        else:
+            xs = sp.csr_matrix(sp.diags(np.asarray(support_mask, dtype=np.float32)) @ x)
+            xs.eliminate_zeros()
+        xt = sp.csr_matrix(xs.T)
+        xt.sort_indices()
+        cg = _make_csr(x.indptr, x.indices, x.data, C_, G_, device, chunk)
+        gc = _make_csr(xt.indptr, xt.indices, xt.data, G_, C_, device, chunk)
+        return CellGeneGraph(G_, C_, cg, gc, 0, C_)
+
+    @staticmethod
+    def from_device_csr(rowptr: torch.Tensor, col: torch.Tensor, raw: torch.Tensor, num_genes: int,
+                        chunk: int = DEFAULT_CHUNK) -> "CellGeneGraph":
+        """Build from a device CSR of the (cells x genes) raw expression (all cells are support cells)."""
+        dev = col.device
+        C_ = rowptr.shape[0] - 1
+        rowptr = rowptr.to(torch.int32).contiguous()
+        col = col.to(torch.int32).contiguous()
+        raw = raw.to(torch.float32).contiguous()
+        val, inv_deg = _normalize_on_device(rowptr, raw)
+        host = rowptr.cpu().numpy()
+        cg = AggCsr(rowptr, col, val, inv_deg, C_, num_genes, build_plan(host, chunk, device=dev), host)
+        # transpose the RAW values, then normalise per gene
+        counts = torch.bincount(col.long(), minlength=num_genes)
+        t_rowptr = torch.zeros(num_genes + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(counts, 0, out=t_rowptr[1:])
+        rows = torch.repeat_interleave(torch.arange(C_, device=dev, dtype=torch.int32), (rowptr[1:] - rowptr[:-1]).long())
+        order = torch.sort(col.long(), stable=True).indices
+        t_col = rows[order].contiguous()
+        t_raw = raw[order].contiguous()
+        del rows, order
+        t_rowptr = t_rowptr.to(torch.int32)
+        t_val, t_inv = _normalize_on_device(t_rowptr, t_raw)
+        thost = t_rowptr.cpu().numpy()
+        gc = AggCsr(t_rowptr, t_col, t_val, t_inv, num_genes, C_, build_plan(thost, chunk, device=dev), thost)
+        return CellGeneGraph(num_genes, C_, cg, gc, 0, C_)
+
+    def bytes_resident(self) -> int:
+        tot = 0
+        for d in (self.cg, self.gc):
+            for t in (d.rowptr, d.col, d.val, d.inv_deg, d.plan.items, d.plan.long_rows):
+                tot += t.numel() * t.element_size()
+        return tot

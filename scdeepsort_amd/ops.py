@@ -1,0 +1,241 @@
+"""Host-side operators of the hot path: thin wrappers over the C ABI (``include/wgnn.h``)
+plus the ``torch.autograd.Function`` that stands where the reference calls
+
+    nf.block_compute(i, self.message_func, fn.mean('m', 'neigh'), layer)   (models/gnn.py:65)
+
+torch is used for device memory, streams and autograd bookkeeping only; all
+aggregation arithmetic runs in the HIP kernels.  There is no CPU fallback: a
+non-CUDA tensor or a missing ``libwgnn_hip.so`` raises ``WgnnError``.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import DST_IS_GENE, NO_ALPHA, SRC_IS_GENE, WgnnError
+from .graph import AggCsr, Plan, _ptr, _stream
+
+
+def _require_cuda(*ts: Optional[torch.Tensor]) -> torch.device:
+    dev = None
+    for t in ts:
+        if t is None:
+            continue
+        if t.device.type != "cuda":
+            raise WgnnError("wgnn operators run on the GPU only (tensor on %s); there is no CPU fallback" % t.device)
+        dev = t.device
+    return dev
+
+
+def _rowmajor(t: torch.Tensor) -> torch.Tensor:
+    if t.dim() != 2:
+        raise ValueError("expected a 2-D feature matrix")
+    if t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16:
+        t = t.contiguous()
+    return t
+
+
+def _dtype_code(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return _lib.F32
+    if t.dtype == torch.float16:
+        return _lib.F16
+    raise WgnnError(f"unsupported feature dtype {t.dtype}")
+
+
+# Optional launch-level timing hook (bench.py): when set to a list, every K1 call appends
+# (tag, start_event, end_event) recorded on the stream the kernels are enqueued on.
+PROFILE = None
+
+
+def _partials(plan: Plan, D: int, device) -> Optional[torch.Tensor]:
+    return torch.empty(plan.n_partials * D, dtype=torch.float32, device=device) if plan.n_partials else None
+
+
+def agg_fwd(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, self_idx: int,
+            h_src: torch.Tensor, h_self: Optional[torch.Tensor], *, bias: Optional[torch.Tensor] = None,
+            relu: bool = False, row_ids: Optional[torch.Tensor] = None, self_compact: bool = False,
+            no_mean: bool = False, out_dtype: Optional[torch.dtype] = None,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """K1 ``wgnn_agg_fwd``: weighted mean of in-neighbours incl. the implicit self-loop."""
+    dev = _require_cuda(h_src, h_self, alpha, bias, csr.col)
+    h_src = _rowmajor(h_src)
+    D = h_src.shape[1]
+    if D % 4:
+        raise WgnnError(f"feature width {D} must be a multiple of 4")
+    if h_self is not None:
+        h_self = _rowmajor(h_self)
+        if h_self.dtype != h_src.dtype or h_self.shape[1] != D:
+            raise WgnnError("h_self must match h_src in dtype and width")
+    if row_ids is not None:
+        ids, plan = csr.subplan(row_ids)
+        n_out = ids.shape[0]
+    else:
+        ids, plan, n_out = None, csr.plan, csr.n_rows
+    out_dtype = out_dtype or h_src.dtype
+    if out is None:
+        out = torch.empty((n_out, D), dtype=out_dtype, device=dev)
+    flags = (_lib.FLAG_RELU if relu else 0) | (_lib.FLAG_NO_MEAN if no_mean else 0) | \
+            (_lib.FLAG_NO_SELF if h_self is None else 0) | (_lib.FLAG_SELF_COMPACT if self_compact else 0)
+    if alpha is not None:
+        alpha = alpha.reshape(-1)
+        if alpha.dtype != torch.float32 or not alpha.is_contiguous():
+            alpha = alpha.float().contiguous()
+    if bias is not None:
+        bias = bias.float().contiguous()
+    part = _partials(plan, D, dev)
+    ev = None
+    if PROFILE is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record(torch.cuda.current_stream(dev))
+    rc = _lib.lib().wgnn_agg_fwd(
+        _ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), _ptr(alpha), mode, self_idx,
+        _ptr(h_src), h_src.stride(0), _ptr(h_self), h_self.stride(0) if h_self is not None else 0,
+        _ptr(ids), _ptr(csr.inv_deg), _ptr(bias), _ptr(out), out.stride(0), n_out, D,
+        _dtype_code(h_src), _dtype_code(out), flags,
+        _ptr(plan.items), plan.n_items, _ptr(plan.long_rows) if plan.n_long else None, plan.n_long,
+        _ptr(part), plan.n_partials, _stream(dev))
+    _lib.check(rc, "wgnn_agg_fwd")
+    if ev is not None:
+        ev[1].record(torch.cuda.current_stream(dev))
+        PROFILE.append((("rows", csr.n_rows, "cols", csr.n_cols, "nnz", csr.nnz, "D", D, "mode", mode), ev[0], ev[1]))
+    return out
+
+
+def agg_bwd_src(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, g: torch.Tensor,
+                h_src: Optional[torch.Tensor], dalpha: Optional[torch.Tensor] = None,
+                dh_src: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """K2 ``wgnn_agg_bwd_src``: gradient w.r.t. the gathered rows (transposed SpMM);
+    for SRC_IS_GENE also writes dalpha[0:n_src] = <h_src[s], T[s]>."""
+    dev = _require_cuda(g, h_src, alpha)
+    t = csr.transposed()
+    g = _rowmajor(g.float())
+    D = g.shape[1]
+    if g.shape[0] != csr.n_rows:
+        raise WgnnError("g must have one row per destination row of the CSR")
+    if dh_src is None:
+        dh_src = torch.empty((t.n_rows, D), dtype=torch.float32, device=dev)
+        accumulate = False
+    if h_src is not None:
+        h_src = _rowmajor(h_src.float())
+    if alpha is not None:
+        alpha = alpha.reshape(-1).float().contiguous()
+    part = _partials(t.plan, D, dev)
+    rc = _lib.lib().wgnn_agg_bwd_src(
+        _ptr(t.rowptr), _ptr(t.col), _ptr(t.val), _ptr(alpha), mode, _ptr(csr.inv_deg),
+        _ptr(g), g.stride(0), _ptr(h_src), h_src.stride(0) if h_src is not None else 0,
+        _ptr(dh_src), dh_src.stride(0), _ptr(dalpha), int(accumulate), t.n_rows, D,
+        _ptr(t.plan.items), t.plan.n_items, _ptr(t.plan.long_rows) if t.plan.n_long else None, t.plan.n_long,
+        _ptr(part), t.plan.n_partials, _stream(dev))
+    _lib.check(rc, "wgnn_agg_bwd_src")
+    return dh_src
+
+
+def agg_bwd_alpha(csr: AggCsr, g: torch.Tensor, h_src: torch.Tensor, h_self: Optional[torch.Tensor],
+                  row_ids: Optional[torch.Tensor] = None, self_compact: bool = False):
+    """K3 ``wgnn_agg_bwd_alpha``: per-row alpha gradients for DST_IS_GENE rows and the self-loop scalar."""
+    dev = _require_cuda(g, h_src, h_self)
+    g = _rowmajor(g.float()); h_src = _rowmajor(h_src.float())
+    D = g.shape[1]
+    if row_ids is not None:
+        ids, plan = csr.subplan(row_ids)
+        n_out = ids.shape[0]
+    else:
+        ids, plan, n_out = None, csr.plan, csr.n_rows
+    if h_self is not None:
+        h_self = _rowmajor(h_self.float())
+    d_row = torch.empty(n_out, dtype=torch.float32, device=dev)
+    d_self = torch.empty(n_out, dtype=torch.float32, device=dev) if h_self is not None else None
+    part = _partials(plan, D, dev)
+    rc = _lib.lib().wgnn_agg_bwd_alpha(
+        _ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), _ptr(csr.inv_deg), _ptr(ids),
+        _ptr(g), g.stride(0), _ptr(h_src), h_src.stride(0), _ptr(h_self), h_self.stride(0) if h_self is not None else 0,
+        _ptr(d_row), _ptr(d_self), n_out, D, _lib.FLAG_SELF_COMPACT if self_compact else 0,
+        _ptr(plan.items), plan.n_items, _ptr(plan.long_rows) if plan.n_long else None, plan.n_long,
+        _ptr(part), plan.n_partials, _stream(dev))
+    _lib.check(rc, "wgnn_agg_bwd_alpha")
+    return d_row, d_self
+
+
+class WeightedMeanAggregate(torch.autograd.Function):
+    """Differentiable ``block_compute(message_func, fn.mean)`` (+ fused bias / ReLU).
+
+    forward  = K1;  backward = K2 (dh_src, dalpha[genes] for gene->cell edges),
+    K3 (dalpha for cell->gene edges + self-loop scalar) and a row scale for dh_self.
+    Gradients follow train.py:84's autograd through gnn.py:47-56,65:
+      dh[u]     = sum_{e=(u->v)} alpha[k(e)] w_e g[v]/deg(v)
+      dalpha[k] = sum_{e:k(e)=k} w_e <g[v], h[u]>/deg(v)           (w has no grad)
+    """
+
+    @staticmethod
+    def forward(ctx, h_src, h_self, alpha, bias, csr: AggCsr, mode: int, self_idx: int, relu: bool,
+                row_ids, self_compact: bool):
+        out = agg_fwd(csr, alpha, mode, self_idx, h_src, h_self, bias=bias, relu=relu, row_ids=row_ids,
+                      self_compact=self_compact)
+        ctx.csr, ctx.mode, ctx.self_idx, ctx.relu, ctx.self_compact = csr, mode, self_idx, relu, self_compact
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(h_src, h_self, alpha, out if relu else None, row_ids)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        h_src, h_self, alpha, out, row_ids = ctx.saved_tensors
+        csr: AggCsr = ctx.csr
+        mode, self_idx = ctx.mode, ctx.self_idx
+        g = gout.float()
+        if ctx.relu:
+            g = g * (out > 0)
+        g = g.contiguous()
+        dbias = g.sum(0) if ctx.has_bias else None
+        D = g.shape[1]
+        dev = g.device
+        a = alpha.reshape(-1)
+        rows = row_ids.long() if row_ids is not None else None
+        inv_rows = csr.inv_deg if rows is None else csr.inv_deg[rows]
+        # destination-row gradient over ALL csr rows (K2 walks the transposed structure)
+        if rows is None:
+            g_full = g
+        else:
+            g_full = torch.zeros((csr.n_rows, D), dtype=torch.float32, device=dev)
+            g_full[rows] = g
+        dalpha = torch.zeros_like(a) if ctx.needs_input_grad[2] else None
+        need_src = ctx.needs_input_grad[0]
+        dh_src = None
+        if need_src or (dalpha is not None and mode == SRC_IS_GENE):
+            dh_src = agg_bwd_src(csr, a if mode != NO_ALPHA else None, mode, g_full,
+                                 h_src if (dalpha is not None and mode == SRC_IS_GENE) else None, dalpha)
+            dh_src = dh_src.to(h_src.dtype)
+        dh_self = None
+        hs_rows = None
+        if h_self is not None:
+            hs_rows = h_self if (rows is None or ctx.self_compact) else h_self[rows]
+            coef = (a[self_idx] if mode != NO_ALPHA else 1.0) * inv_rows
+            if ctx.needs_input_grad[1]:
+                d = (g * coef.unsqueeze(1)).to(h_self.dtype)
+                if rows is None or ctx.self_compact:
+                    dh_self = d
+                else:
+                    dh_self = torch.zeros_like(h_self)
+                    dh_self[rows] = d
+        if dalpha is not None and mode != NO_ALPHA:
+            if mode == DST_IS_GENE:
+                d_row, d_self = agg_bwd_alpha(csr, g, h_src, hs_rows, row_ids, self_compact=True if rows is not None else False)
+                if rows is None:
+                    dalpha[: csr.n_rows] += d_row
+                else:
+                    dalpha.index_add_(0, rows, d_row)
+                if d_self is not None:
+                    dalpha[self_idx] += d_self.sum()
+            elif hs_rows is not None:
+                dalpha[self_idx] += ((g * hs_rows.float()).sum(1) * inv_rows).sum()
+        if dalpha is not None:
+            dalpha = dalpha.reshape(alpha.shape)
+        return dh_src, dh_self, dalpha, dbias, None, None, None, None, None, None
+
+
+def weighted_mean_aggregate(csr: AggCsr, alpha: torch.Tensor, mode: int, self_idx: int, h_src: torch.Tensor,
+                            h_self: Optional[torch.Tensor], bias: Optional[torch.Tensor] = None, relu: bool = False,
+                            row_ids: Optional[torch.Tensor] = None, self_compact: bool = False) -> torch.Tensor:
+    return WeightedMeanAggregate.apply(h_src, h_self, alpha, bias, csr, mode, self_idx, relu, row_ids, self_compact)

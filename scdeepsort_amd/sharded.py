@@ -1,0 +1,84 @@
+"""Binding of the cell-shard orchestration (``dist.py``) to the HIP operators.
+
+``ShardedWgnn`` owns one rank's shard of the graph: its cells' rows of the cells<-genes CSR,
+the genes<-cells CSR restricted to its cells (globally normalised), and a replicated gene table.
+With ``world_size == 1`` it degenerates to the plain single-GPU ``GNN.forward``.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from . import dist as D
+from ._lib import NO_ALPHA, SRC_IS_GENE
+from .gnn import GNN
+from .graph import AggCsr, CellGeneGraph, _normalize_on_device, build_plan, DEFAULT_CHUNK
+from .ops import agg_fwd
+
+
+class ShardedWgnn:
+    def __init__(self, model: GNN, graph: CellGeneGraph, world: int):
+        self.model, self.graph, self.world = model, graph, world
+
+    @property
+    def nnz(self) -> int:
+        return self.graph.cg.nnz
+
+    @staticmethod
+    def build(model: GNN, rowptr: torch.Tensor, col: torch.Tensor, raw: torch.Tensor, num_genes: int,
+              chunk: int = DEFAULT_CHUNK) -> "ShardedWgnn":
+        """``rowptr/col/raw``: device CSR of THIS rank's (cells x genes) raw expression."""
+        rank, world = D.world()
+        g = CellGeneGraph.from_device_csr(rowptr, col, raw, num_genes, chunk)
+        if world > 1:
+            # gene side: w = deg_glob * x / sum_glob over ALL ranks' cells (preprocess_internal.py:17-23)
+            gc = g.gc
+            deg_loc = (gc.rowptr[1:] - gc.rowptr[:-1]).float()
+            row_of = torch.repeat_interleave(torch.arange(num_genes, device=col.device, dtype=torch.int32),
+                                             (gc.rowptr[1:] - gc.rowptr[:-1]).long())
+            sum_loc = torch.zeros(num_genes, dtype=torch.float64, device=col.device)
+            sum_loc.index_add_(0, col.long(), raw.double())
+            gc.val, gc.inv_deg = D.normalise_gene_side(deg_loc, sum_loc, gc.val, row_of)
+            gc._t = None
+        return ShardedWgnn(model, g, world)
+
+    # -- local arithmetic bound to the HIP kernels -------------------------------------------------
+    def _ops(self) -> D.LocalOps:
+        m, g = self.model, self.graph
+        G = g.num_genes
+        a = m.alpha.reshape(-1)
+
+        def cells_layer(p_g, p_c, b, relu):
+            return agg_fwd(g.cg, a, SRC_IS_GENE, G + 1, p_g, p_c, bias=b, relu=relu)
+
+        def genes_partial(p_c):
+            return agg_fwd(g.gc, None, NO_ALPHA, 0, p_c, None, no_mean=True)
+
+        def genes_finish(part, p_g, b, relu):
+            z = (a[:G].unsqueeze(1) * part + a[G] * p_g) * g.gc.inv_deg.unsqueeze(1) + b
+            return F.relu(z) if relu else z
+
+        return D.LocalOps(cells_layer, genes_partial, genes_finish)
+
+    def forward(self, feats_g: torch.Tensor, feats_c_local: torch.Tensor, gather_logits: bool = True) -> torch.Tensor:
+        m = self.model
+        if self.world == 1:
+            return m.linear(m.embed(self.graph, (feats_g, feats_c_local)))
+        weights = [(l.fc_neigh.weight, l.fc_neigh.bias) for l in m.layers] + [(m.linear.weight, m.linear.bias)]
+        return D.sharded_forward(weights, None, feats_g, feats_c_local, self._ops(), m.n_layers, gather_logits)
+
+    def forward_alg_bytes(self, dense_dim: int, s: int = 4) -> int:
+        """Algorithmic HBM bytes of one 2-layer forward on this rank (SURVEY.md section 8d formula)."""
+        g, m = self.graph, self.model
+        G, C = g.num_genes, g.num_cells
+        H = m.layers[0].fc_neigh.weight.shape[0]
+        def b(nnz, R, S, din, dout):
+            return 8 * nnz + 4 * (R + 1) + s * din * (S + R) + 4 * G + s * dout * R
+        tot, din = 0, dense_dim
+        for i in range(m.n_layers):
+            last = i == m.n_layers - 1
+            if not last:
+                tot += b(g.gc.nnz, G, C, din, H)
+            tot += b(g.cg.nnz, C, G, din, H)
+            din = H
+        return tot

@@ -1,0 +1,123 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads without a GPU, exports every
+symbol include/wgnn.h declares, validates arguments before touching HIP, and its host-side plan
+builder is correct.  No compute is launched here."""
+import ctypes as C
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+
+import scdeepsort_amd as sda
+from scdeepsort_amd import _lib
+from scdeepsort_amd.graph import build_plan
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def declared_symbols():
+    text = (ROOT / "include" / "wgnn.h").read_text()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(wgnn_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.lib()
+    syms = declared_symbols()
+    assert {"wgnn_agg_fwd", "wgnn_agg_bwd_src", "wgnn_agg_bwd_alpha", "wgnn_normalize_rows",
+            "wgnn_plan_build_host", "wgnn_version", "wgnn_last_error_string"} <= set(syms)
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in wgnn.h but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in _lib.py"
+    assert lib.wgnn_version() == 100
+    assert b"ok" == lib.wgnn_last_error_string(0)
+
+
+def test_header_enums_match_python():
+    text = (ROOT / "include" / "wgnn.h").read_text()
+    def val(name):
+        return int(re.search(rf"#define\s+{name}\s+(-?\d+)", text).group(1))
+    assert (val("WGNN_SRC_IS_GENE"), val("WGNN_DST_IS_GENE"), val("WGNN_NO_ALPHA")) == (sda.SRC_IS_GENE, sda.DST_IS_GENE, sda.NO_ALPHA)
+    assert (val("WGNN_F32"), val("WGNN_F16")) == (_lib.F32, _lib.F16)
+    assert (val("WGNN_FLAG_RELU"), val("WGNN_FLAG_NO_MEAN"), val("WGNN_FLAG_NO_SELF"), val("WGNN_FLAG_SELF_COMPACT")) == \
+           (_lib.FLAG_RELU, _lib.FLAG_NO_MEAN, _lib.FLAG_NO_SELF, _lib.FLAG_SELF_COMPACT)
+
+
+def test_argument_validation_returns_error_codes_without_gpu():
+    lib = _lib.lib()
+    one = C.c_void_p(16)      # fake, aligned, never dereferenced: validation happens first
+    def fwd(D=8, ld=8, mode=0, alpha=one, n_items=0, dtype=0):
+        return lib.wgnn_agg_fwd(one, one, one, alpha, mode, 0, one, ld, one, ld, None, None, None, one, ld, 4, D,
+                                dtype, 0, 0, None, n_items, None, 0, None, 0, None)
+    assert fwd(D=6) == -2                       # D % 4
+    assert fwd(ld=6) == -2                      # ld % 4
+    assert fwd(D=2048, ld=2048) == -3           # too wide
+    assert fwd(mode=7) == -1
+    assert fwd(alpha=None) == -1                # alpha required unless NO_ALPHA
+    assert fwd(n_items=3) == -1                 # items missing
+    assert fwd(dtype=5) == -3
+    assert lib.wgnn_normalize_rows(None, one, one, None, 4, None) == -1
+    assert lib.wgnn_normalize_rows(one, one, one, None, 0, None) == 0      # empty input is a no-op
+    for code in (-1, -2, -3, -4, -5, -6):
+        assert len(lib.wgnn_last_error_string(code)) > 3
+
+
+def test_plan_builder_chunks_long_rows():
+    nnz = np.array([0, 5, 2048, 2049, 10000, 1, 0, 4096])
+    rowptr = np.concatenate([[0], np.cumsum(nnz)]).astype(np.int32)
+    plan = build_plan(rowptr, chunk=2048)
+    items, longs = plan.items.numpy(), plan.long_rows.numpy()
+    # every row is covered exactly once, in order, by contiguous chunks of <= chunk nnz
+    covered = {r: [] for r in range(len(nnz))}
+    for r, b, e, slot in items:
+        assert 0 <= e - b <= 2048
+        covered[r].append((b, e, slot))
+    for r, n in enumerate(nnz):
+        segs = covered[r]
+        assert segs[0][0] == rowptr[r] and segs[-1][1] == rowptr[r + 1]
+        for (b0, e0, _), (b1, e1, _) in zip(segs, segs[1:]):
+            assert e0 == b1
+        if n <= 2048:
+            assert len(segs) == 1 and segs[0][2] == -1
+        else:
+            assert len(segs) == -(-n // 2048) and all(s[2] >= 0 for s in segs)
+    assert [int(l[0]) for l in longs] == [3, 4, 7]
+    assert [int(l[2]) for l in longs] == [2, 5, 2]
+    assert plan.n_partials == 9
+    slots = sorted(int(s[2]) for segs in covered.values() for s in segs if s[2] >= 0)
+    assert slots == list(range(9))
+    for r, first, n, _ in longs:
+        assert [s[2] for s in covered[r]] == list(range(first, first + n))
+
+
+def test_plan_builder_row_subset():
+    nnz = np.array([3, 0, 7, 5000, 2])
+    rowptr = np.concatenate([[0], np.cumsum(nnz)]).astype(np.int32)
+    ids = np.array([3, 0, 3], dtype=np.int32)          # repeated seed, arbitrary order
+    plan = build_plan(rowptr, chunk=2048, row_ids_host=ids)
+    items = plan.items.numpy()
+    assert sorted(set(items[:, 0].tolist())) == [0, 1, 2]        # slots, not row ids
+    assert plan.n_long == 2 and plan.n_partials == 6
+    for slot, b, e, _ in items:
+        r = ids[slot]
+        assert rowptr[r] <= b <= e <= rowptr[r + 1]
+
+
+def test_product_path_fails_loudly_without_gpu_tensors():
+    """No CPU fallback: CPU tensors (or a missing .so) must raise, never silently compute."""
+    rowptr = np.array([0, 1, 2], dtype=np.int32)
+    plan = build_plan(rowptr)
+    csr = sda.AggCsr(torch.tensor([0, 1, 2], dtype=torch.int32), torch.tensor([0, 1], dtype=torch.int32),
+                     torch.ones(2), torch.ones(2), 2, 2, plan, rowptr)
+    with pytest.raises(sda.WgnnError):
+        sda.agg_fwd(csr, torch.ones(4), sda.SRC_IS_GENE, 3, torch.ones(2, 4), torch.ones(2, 4))
+    import scipy.sparse as sp
+    with pytest.raises(sda.WgnnError):
+        sda.CellGeneGraph.from_expression(sp.csr_matrix(np.eye(3, dtype=np.float32)), device="cpu")
+
+
+def test_no_product_module_imports_the_oracle():
+    for f in (ROOT / "scdeepsort_amd").rglob("*.py"):
+        src = f.read_text()
+        assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# oracle", ""), f

@@ -1,0 +1,224 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on identical inputs.
+Tolerance: 1e-4 absolute on O(1) fp32 values (BASELINE.json north_star); index/plan work is exact."""
+import json
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+import torch.nn.functional as F
+
+import scdeepsort_amd as sda
+from conftest import GOLDEN, load_golden, small_case
+from oracle import wgnn_oracle as O
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+DEV = "cuda:0"
+
+
+def dev(x, dtype=torch.float32):
+    return torch.as_tensor(x, dtype=dtype, device=DEV)
+
+
+def make_model(sd, dim, hidden, n_classes, n_layers, G, order="auto"):
+    m = sda.GNN(dim, hidden, n_classes, n_layers, G, activation=F.relu).to(DEV)
+    m.load_state_dict(sd)
+    m.order = order
+    return m.eval()
+
+
+def test_library_loaded_and_gpu_present():
+    assert torch.cuda.is_available()
+    assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
+    from scdeepsort_amd import _lib
+    assert _lib.lib().wgnn_version() == 100
+
+
+def test_kat_2x2_on_gpu():
+    kat = json.loads((GOLDEN / "kat_2x2.json").read_text())
+    expr = sp.csr_matrix(np.array(kat["expr_rows"], dtype=np.float32))
+    g = sda.CellGeneGraph.from_expression(expr, device=DEV)
+    # K4 normalisation, hand-derived values
+    np.testing.assert_allclose(g.cg.val.cpu().numpy(), [0.5, 1.5, 1.0], rtol=1e-6)         # into c0: g0,g1 ; into c1: g0
+    np.testing.assert_allclose(g.gc.val.cpu().numpy(), [2 / 3, 4 / 3, 1.0], rtol=1e-6)     # into g0: c0,c1 ; into g1: c0
+    np.testing.assert_allclose(g.cg.inv_deg.cpu().numpy(), [1 / 3, 1 / 2], rtol=1e-6)
+    alpha = dev(kat["alpha"])
+    x = torch.zeros(4, 4, device=DEV); x[:, 0] = dev(kat["features"])                       # D padded to 4
+    zc = sda.agg_fwd(g.cg, alpha, sda.SRC_IS_GENE, 3, x[:2], x[2:])
+    zg = sda.agg_fwd(g.gc, alpha, sda.DST_IS_GENE, 2, x[2:], x[:2])
+    got = torch.cat([zg[:, 0], zc[:, 0]]).cpu().numpy()
+    np.testing.assert_allclose(got, [kat["neigh"][k] for k in ("g0", "g1", "c0", "c1")], rtol=1e-6)
+    assert torch.all(zc[:, 1:] == 0)
+
+
+@pytest.mark.parametrize("D", [4, 8, 24, 32, 64, 100, 128, 256, 400, 1024])
+@pytest.mark.parametrize("mode", ["cells", "genes"])
+def test_aggregate_widths_and_modes(D, mode):
+    c = small_case(cells=200, genes=150, dim=D, seed=D, density=0.3)
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV, chunk=32)   # forces long-row splitting
+    cg = O.build_csr_graph(c["expr"], c["support_mask"])
+    G = c["G"]
+    alpha = np.random.default_rng(1).uniform(0.5, 1.5, G + 2).astype(np.float32)
+    Hg, Hc = c["feats"][:G], c["feats"][G:]
+    zc, zg = O.csr_aggregate(cg, alpha, Hg.astype(np.float64), Hc.astype(np.float64))
+    if mode == "cells":
+        out = sda.agg_fwd(g.cg, dev(alpha), sda.SRC_IS_GENE, G + 1, dev(Hg), dev(Hc))
+        np.testing.assert_allclose(out.cpu().numpy(), zc, atol=TOL)
+        assert g.cg.plan.n_long > 0
+    else:
+        out = sda.agg_fwd(g.gc, dev(alpha), sda.DST_IS_GENE, G, dev(Hc), dev(Hg))
+        np.testing.assert_allclose(out.cpu().numpy(), zg, atol=TOL)
+
+
+def test_fused_bias_relu_and_flags():
+    c = small_case(seed=11, dim=32)
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
+    cg = O.build_csr_graph(c["expr"], c["support_mask"])
+    G = c["G"]; rng = np.random.default_rng(2)
+    alpha = rng.uniform(0.5, 1.5, G + 2).astype(np.float32); bias = rng.standard_normal(32).astype(np.float32)
+    Hg, Hc = c["feats"][:G], c["feats"][G:]
+    zc, _ = O.csr_aggregate(cg, alpha, Hg.astype(np.float64), Hc.astype(np.float64))
+    out = sda.agg_fwd(g.cg, dev(alpha), sda.SRC_IS_GENE, G + 1, dev(Hg), dev(Hc), bias=dev(bias), relu=True)
+    np.testing.assert_allclose(out.cpu().numpy(), np.maximum(zc + bias, 0), atol=TOL)
+    # NO_ALPHA + NO_MEAN + no self = plain A @ H (multi-GPU partial sums; cell-feature build)
+    raw = sda.agg_fwd(g.cg, None, sda.NO_ALPHA, 0, dev(Hg), None, no_mean=True)
+    np.testing.assert_allclose(raw.cpu().numpy(), cg.A_cg.astype(np.float64) @ Hg.astype(np.float64), atol=2e-4, rtol=1e-5)
+
+
+def test_seed_subset_and_order():
+    """row_ids = the seed list of a NodeFlow batch: arbitrary order, repeats allowed (predict.py:75-76)."""
+    c = small_case(seed=12, dim=64)
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV, chunk=16)
+    cg = O.build_csr_graph(c["expr"], c["support_mask"])
+    G = c["G"]; alpha = np.random.default_rng(3).uniform(0.5, 1.5, G + 2).astype(np.float32)
+    Hg, Hc = c["feats"][:G], c["feats"][G:]
+    zc, _ = O.csr_aggregate(cg, alpha, Hg.astype(np.float64), Hc.astype(np.float64))
+    ids = torch.tensor([5, 3, 90, 3, 0, 95], device=DEV)
+    out = sda.agg_fwd(g.cg, dev(alpha), sda.SRC_IS_GENE, G + 1, dev(Hg), dev(Hc), row_ids=ids)
+    np.testing.assert_allclose(out.cpu().numpy(), zc[ids.cpu().numpy()], atol=TOL)
+    out2 = sda.agg_fwd(g.cg, dev(alpha), sda.SRC_IS_GENE, G + 1, dev(Hg), dev(Hc)[ids], row_ids=ids, self_compact=True)
+    assert torch.equal(out, out2)
+    empty = sda.agg_fwd(g.cg, dev(alpha), sda.SRC_IS_GENE, G + 1, dev(Hg), dev(Hc), row_ids=ids[:0])
+    assert empty.shape == (0, 64)
+
+
+def test_fp16_feature_storage_fp32_accumulate():
+    c = small_case(seed=13, dim=128)
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
+    cg = O.build_csr_graph(c["expr"], c["support_mask"])
+    G = c["G"]; alpha = np.random.default_rng(4).uniform(0.5, 1.5, G + 2).astype(np.float32)
+    f16 = c["feats"].astype(np.float16)
+    zc, _ = O.csr_aggregate(cg, alpha, f16[:G].astype(np.float64), f16[G:].astype(np.float64))   # same rounded inputs
+    out = sda.agg_fwd(g.cg, dev(alpha), sda.SRC_IS_GENE, G + 1, dev(f16[:G], torch.float16), dev(f16[G:], torch.float16),
+                      out_dtype=torch.float32)
+    np.testing.assert_allclose(out.cpu().numpy(), zc, atol=TOL)
+    out16 = sda.agg_fwd(g.cg, dev(alpha), sda.SRC_IS_GENE, G + 1, dev(f16[:G], torch.float16), dev(f16[G:], torch.float16))
+    assert out16.dtype == torch.float16
+    np.testing.assert_allclose(out16.float().cpu().numpy(), zc, atol=2e-3)
+
+
+@pytest.mark.parametrize("name", ["testis199", "pancreas11"])
+@pytest.mark.parametrize("order", ["project_first", "aggregate_first"])
+def test_golden_forward(name, order):
+    c = load_golden(name)
+    z = c["z"]
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
+    m = make_model(c["sd"], int(z["dim"]), int(z["hidden"]), int(z["n_classes"]), c["n_layers"], c["G"], order)
+    with torch.no_grad():
+        logits = m(g, dev(c["feats"])).cpu().numpy()
+        emb = m.embed(g, dev(c["feats"])).cpu().numpy()
+    np.testing.assert_allclose(logits, z["logits_f64"], atol=TOL)
+    np.testing.assert_allclose(logits, z["logits_f32"], atol=TOL)
+    np.testing.assert_allclose(emb, z["hidden_last_f32"], atol=TOL)
+
+
+def test_forward_seeds_match_nodeflow_batches():
+    c = small_case(seed=14)
+    sd = O.init_params(c["dim"], c["hidden"], c["n_classes"], 2, c["G"], seed=5)
+    rg = O.build_reference_graph(c["expr"], c["support_mask"])
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
+    m = make_model(sd, c["dim"], c["hidden"], c["n_classes"], 2, c["G"])
+    rng = np.random.default_rng(1)
+    seeds = rng.permutation(np.arange(c["G"], c["G"] + c["C"]))[:40]
+    want = O.nodeflow_forward(sd, rg, torch.from_numpy(c["feats"]), seeds, 2).numpy()
+    with torch.no_grad():
+        got = m(g, dev(c["feats"]), seeds=torch.from_numpy(seeds).to(DEV)).cpu().numpy()
+    np.testing.assert_allclose(got, want, atol=TOL)
+
+
+@pytest.mark.parametrize("n_layers,order", [(1, "auto"), (2, "project_first"), (2, "aggregate_first")])
+def test_training_gradients_match_autograd_oracle(n_layers, order):
+    """loss = CE_sum on a seed batch; grads of every parameter incl. alpha (train.py:34-36,80-84)."""
+    c = small_case(cells=80, genes=48, dim=16, hidden=12, n_classes=4, seed=15, test_cells=0)
+    sd = O.init_params(16, 12, 4, n_layers, 48, seed=6)
+    rg = O.build_reference_graph(c["expr"])
+    seeds = np.array([48 + i for i in (0, 5, 9, 33, 70, 3)])        # includes the empty cell (row 3)
+    labels = torch.tensor([0, 1, 2, 3, 1, 0])
+    loss, grads, _ = O.loss_and_grads(sd, rg, torch.from_numpy(c["feats"]), seeds, labels, n_layers)
+    g = sda.CellGeneGraph.from_expression(c["expr"], device=DEV, chunk=8)
+    m = make_model(sd, 16, 12, 4, n_layers, 48, order)
+    logits = m(g, dev(c["feats"]), seeds=torch.from_numpy(seeds).to(DEV))
+    l = F.cross_entropy(logits, labels.to(DEV), reduction="sum")
+    l.backward()
+    assert l.item() == pytest.approx(float(loss), rel=1e-5)
+    for k, p in m.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), grads[k].numpy(), atol=2e-4, rtol=1e-3, err_msg=k)
+
+
+def test_golden_gradients():
+    c = load_golden("testis199"); z = c["z"]
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
+    m = make_model(c["sd"], int(z["dim"]), int(z["hidden"]), int(z["n_classes"]), c["n_layers"], c["G"])
+    logits = m(g, dev(c["feats"]), seeds=torch.from_numpy(z["seeds"]).to(DEV))
+    l = F.cross_entropy(logits, torch.from_numpy(z["labels"]).to(DEV), reduction="sum")
+    l.backward()
+    assert l.item() == pytest.approx(float(z["loss"]), rel=1e-5)
+    for k, p in m.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), c["grads"][k], atol=2e-4, rtol=1e-3, err_msg=k)
+
+
+def test_normalize_rows_matches_reference_formula():
+    rng = np.random.default_rng(7)
+    nnz = np.array([0, 1, 5, 64, 65, 1000, 3])
+    rowptr = np.concatenate([[0], np.cumsum(nnz)]).astype(np.int32)
+    raw = rng.uniform(0.5, 7.0, rowptr[-1]).astype(np.float32)
+    from scdeepsort_amd.graph import _normalize_on_device
+    val, inv = _normalize_on_device(dev(rowptr, torch.int32), dev(raw))
+    want = np.empty_like(raw)
+    for r in range(len(nnz)):
+        seg = raw[rowptr[r]:rowptr[r + 1]]
+        if len(seg):
+            want[rowptr[r]:rowptr[r + 1]] = (np.float32(len(seg)) * seg) / np.float32(seg.astype(np.float64).sum())
+    np.testing.assert_allclose(val.cpu().numpy(), want, rtol=2e-6)
+    np.testing.assert_allclose(inv.cpu().numpy(), 1.0 / (nnz + 1), rtol=1e-7)
+
+
+def test_full_size_properties_cfg2():
+    """At BASELINE cfg2 size: oracle parity on a row sample + size-independent properties
+    (linearity in h, seed-subset == full, determinism)."""
+    from scdeepsort_amd import synthetic as S
+    cfg = S.CONFIGS["cfg2"]
+    rp, col, val = S.synth_expression(cfg.cells, cfg.genes, device=DEV)
+    g = sda.CellGeneGraph.from_device_csr(rp, col, val, cfg.genes)
+    G, C = cfg.genes, cfg.cells
+    alpha = torch.rand(G + 2, device=DEV) + 0.5
+    h1 = S.synth_features(G + C, cfg.hidden, device=DEV); h2 = S.synth_features(G + C, cfg.hidden, seed=5, device=DEV)
+    f = lambda h: sda.agg_fwd(g.cg, alpha, sda.SRC_IS_GENE, G + 1, h[:G], h[G:])
+    fg = lambda h: sda.agg_fwd(g.gc, alpha, sda.DST_IS_GENE, G, h[G:], h[:G])
+    z1, z2, z3 = f(h1), f(h2), f(2 * h1 - 0.5 * h2)
+    assert (2 * z1 - 0.5 * z2 - z3).abs().max().item() < 1e-4
+    y1, y2, y3 = fg(h1), fg(h2), fg(2 * h1 - 0.5 * h2)
+    assert (2 * y1 - 0.5 * y2 - y3).abs().max().item() < 1e-4
+    assert torch.equal(z1, f(h1)) and torch.equal(y1, fg(h1))                    # deterministic (no atomics)
+    ids = torch.randperm(C, device=DEV)[:777]
+    sub = sda.agg_fwd(g.cg, alpha, sda.SRC_IS_GENE, G + 1, h1[:G], h1[G:], row_ids=ids)
+    assert torch.equal(sub, z1[ids])
+    # oracle on the same graph (CPU, seconds at this size)
+    expr = S.to_scipy(rp, col, val, G)
+    cg = O.build_csr_graph(expr)
+    zc, zg = O.csr_aggregate(cg, alpha.cpu().numpy(), h1[:G].cpu().numpy().astype(np.float64), h1[G:].cpu().numpy().astype(np.float64))
+    np.testing.assert_allclose(z1.cpu().numpy(), zc, atol=TOL)
+    np.testing.assert_allclose(y1.cpu().numpy(), zg, atol=TOL)
+    np.testing.assert_allclose(g.cg.val.cpu().numpy(), cg.A_cg.data, rtol=3e-6)
+    np.testing.assert_allclose(g.gc.val.cpu().numpy(), cg.A_gc.data, rtol=3e-6)

@@ -1,0 +1,142 @@
+"""CPU tests of the oracle itself: known answers, dual-formulation agreement, algebraic
+properties.  The reference holds no test vectors for this path
+(parity unpinned), so these are what pin the restatement."""
+import json
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from conftest import GOLDEN, load_golden, small_case
+from oracle import wgnn_oracle as O
+
+
+def test_kat_2x2_hand_derived():
+    kat = json.loads((GOLDEN / "kat_2x2.json").read_text())
+    expr = sp.csr_matrix(np.array(kat["expr_rows"], dtype=np.float32))
+    g = O.build_reference_graph(expr)
+    G = kat["genes"]
+    # normalised weights (preprocess_internal.py:17-23), keyed by (src, dst)
+    w = {(int(s), int(d)): float(x) for s, d, x in zip(g.src, g.dst, g.weight)}
+    assert w[(2, 0)] == pytest.approx(kat["norm_w_into_g0"]["c0"], rel=1e-6)
+    assert w[(3, 0)] == pytest.approx(kat["norm_w_into_g0"]["c1"], rel=1e-6)
+    assert w[(2, 1)] == pytest.approx(kat["norm_w_into_g1"]["c0"], rel=1e-6)
+    assert w[(0, 2)] == pytest.approx(kat["norm_w_into_c0"]["g0"], rel=1e-6)
+    assert w[(1, 2)] == pytest.approx(kat["norm_w_into_c0"]["g1"], rel=1e-6)
+    assert w[(0, 3)] == pytest.approx(kat["norm_w_into_c1"]["g0"], rel=1e-6)
+    for n in range(4):
+        assert w[(n, n)] == 1.0                                   # self-loops added after normalisation
+    alpha = torch.tensor(kat["alpha"]).unsqueeze(-1)
+    x = torch.tensor(kat["features"]).unsqueeze(-1)
+    neigh = O.block_compute(x, g.src, g.dst, torch.from_numpy(g.weight), g.node_id, g.node_id, 4, alpha, G).ravel()
+    want = [kat["neigh"][k] for k in ("g0", "g1", "c0", "c1")]
+    np.testing.assert_allclose(neigh.numpy(), want, rtol=1e-6)
+    cg = O.build_csr_graph(expr)
+    zc, zg = O.csr_aggregate(cg, alpha.numpy(), x.numpy()[:G], x.numpy()[G:])
+    np.testing.assert_allclose(np.concatenate([zg.ravel(), zc.ravel()]), want, rtol=1e-6)
+
+
+def test_alpha_index_rules():
+    # gnn.py:49-53 on the four edge kinds (src_id, dst_id): gene->cell, cell->gene, gene loop, cell loop
+    src = np.array([3, -1, 2, -1]); dst = np.array([-1, 4, 2, -1])
+    np.testing.assert_array_equal(O.alpha_index(src, dst, 10), [3, 4, 10, 11])
+
+
+@pytest.mark.parametrize("name", ["testis199", "pancreas11"])
+def test_golden_fixture_reproduces(name):
+    c = load_golden(name)
+    g = O.build_reference_graph(c["expr"], c["support_mask"])
+    logits = O.edgelist_full_forward(c["sd"], g, torch.from_numpy(c["feats"]), c["n_layers"]).numpy()[c["G"]:]
+    np.testing.assert_allclose(logits, c["z"]["logits_f32"], atol=2e-6)
+    cg = O.build_csr_graph(c["expr"], c["support_mask"])
+    csr = O.csr_forward(c["sd"], cg, c["feats"], c["n_layers"])
+    np.testing.assert_allclose(csr, c["z"]["logits_f64"], atol=5e-6)
+
+
+def test_edgelist_vs_csr_random_ragged():
+    c = small_case(seed=1)
+    sd = O.init_params(c["dim"], c["hidden"], c["n_classes"], c["n_layers"], c["G"], seed=2)
+    g = O.build_reference_graph(c["expr"], c["support_mask"])
+    cg = O.build_csr_graph(c["expr"], c["support_mask"])
+    a = O.edgelist_full_forward(sd, g, torch.from_numpy(c["feats"]), c["n_layers"]).numpy()[c["G"]:]
+    b = O.csr_forward(sd, cg, c["feats"], c["n_layers"])
+    np.testing.assert_allclose(a, b, atol=2e-6)
+    assert np.isfinite(a).all()            # empty cell row: only the self-loop, degree 1
+
+
+def test_seed_batching_invariance_eval_mode():
+    """Per-batch NodeFlow (train.py:71-81) == full-graph layer-wise evaluation, any batch split / order."""
+    c = small_case(seed=3)
+    sd = O.init_params(c["dim"], c["hidden"], c["n_classes"], 2, c["G"], seed=4)
+    g = O.build_reference_graph(c["expr"], c["support_mask"])
+    feats = torch.from_numpy(c["feats"])
+    full = O.edgelist_full_forward(sd, g, feats, 2)[c["G"]:]
+    rng = np.random.default_rng(0)
+    seeds = rng.permutation(np.arange(c["G"], c["G"] + c["C"]))
+    for batch in np.array_split(seeds, 5):
+        out = O.nodeflow_forward(sd, g, feats, batch, 2)
+        np.testing.assert_allclose(out.numpy(), full[batch - c["G"]].numpy(), atol=2e-6)
+
+
+def test_unit_alpha_unit_weight_is_plain_mean():
+    c = small_case(seed=5, empty_rows=False, test_cells=0)
+    expr = c["expr"].copy(); expr.data[:] = 1.0        # equal weights -> normalised weight = deg*1/deg = 1
+    cg = O.build_csr_graph(expr)
+    G = c["G"]
+    alpha = np.ones(G + 2, np.float32)
+    Hg, Hc = c["feats"][:G], c["feats"][G:]
+    zc, _ = O.csr_aggregate(cg, alpha, Hg, Hc)
+    dense = (expr.toarray() > 0)
+    want = (dense @ Hg + Hc) / (dense.sum(1, keepdims=True) + 1)
+    np.testing.assert_allclose(zc, want, atol=1e-5)
+
+
+def test_linearity_in_features():
+    c = small_case(seed=6)
+    cg = O.build_csr_graph(c["expr"], c["support_mask"])
+    G = c["G"]
+    rng = np.random.default_rng(1)
+    alpha = rng.uniform(0.5, 1.5, G + 2).astype(np.float32)
+    f1, f2 = c["feats"], rng.standard_normal(c["feats"].shape).astype(np.float32)
+    z1 = O.csr_aggregate(cg, alpha, f1[:G].astype(np.float64), f1[G:].astype(np.float64))
+    z2 = O.csr_aggregate(cg, alpha, f2[:G].astype(np.float64), f2[G:].astype(np.float64))
+    f3 = 2.0 * f1.astype(np.float64) - 0.5 * f2
+    z3 = O.csr_aggregate(cg, alpha, f3[:G], f3[G:])
+    for a, b, cc in zip(z1, z2, z3):
+        np.testing.assert_allclose(2.0 * a - 0.5 * b, cc, atol=1e-10)
+
+
+def test_predict_graph_test_cells_feed_nothing_back():
+    """preprocess.py:184-187: test cells have gene->cell edges only, so gene rows ignore them."""
+    c = small_case(seed=7, test_cells=16)
+    cg = O.build_csr_graph(c["expr"], c["support_mask"])
+    assert cg.A_gc[:, -16:].nnz == 0
+    assert cg.A_cg[-16:, :].nnz > 0
+
+
+def test_gradient_oracle_matches_finite_difference():
+    c = small_case(cells=24, genes=16, dim=8, hidden=6, seed=8, test_cells=0)
+    sd = O.init_params(8, 6, 3, 2, 16, seed=9, dtype=torch.float64)
+    g = O.build_reference_graph(c["expr"])
+    feats = torch.from_numpy(c["feats"]).double()
+    seeds = np.arange(16, 16 + 10)
+    labels = torch.from_numpy(np.random.default_rng(0).integers(0, 3, 10))
+    loss, grads, _ = O.loss_and_grads(sd, g, feats, seeds, labels, 2)
+    eps = 1e-6
+    for key, idx in (("alpha", (3, 0)), ("alpha", (16, 0)), ("alpha", (17, 0)), ("layers.0.fc_neigh.weight", (2, 5))):
+        sp_, sm = {k: v.clone() for k, v in sd.items()}, {k: v.clone() for k, v in sd.items()}
+        sp_[key][idx] += eps; sm[key][idx] -= eps
+        lp = torch.nn.functional.cross_entropy(O.nodeflow_forward(sp_, g, feats, seeds, 2), labels, reduction="sum")
+        lm = torch.nn.functional.cross_entropy(O.nodeflow_forward(sm, g, feats, seeds, 2), labels, reduction="sum")
+        fd = float(lp - lm) / (2 * eps)
+        assert grads[key][idx].item() == pytest.approx(fd, rel=1e-4, abs=1e-7)
+
+
+def test_postprocess_unsure_rule():
+    logits = np.array([[2.0, 0.0, 0.0, 0.0], [0.1, 0.0, 0.05, 0.0]], dtype=np.float32)
+    pred, prob = O.postprocess(logits, unsure_rate=2.0)      # threshold 2/4 = 0.5  (predict.py:82-86)
+    assert pred[0] == 0 and prob[0, 0] > 0.5
+    assert pred[1] == -1
+    pred0, _ = O.postprocess(logits, unsure_rate=0.0)
+    assert (pred0 >= 0).all()
