@@ -113,6 +113,26 @@ int wgnn_agg_fwd(const int32_t* rowptr, const int32_t* col, const float* val,
                  void* stream);
 
 /* ---------------------------------------------------------------------------
+ * K1t forward, LDS-streamed variant of K1 (same arithmetic, same outputs) for D <= 256, f32,
+ *     h_src contiguous (leading dimension == D).  One 1024-thread workgroup per TILE of up to 256
+ *     destination rows; the source table is streamed through LDS in 64-row blocks.
+ *
+ *   tile_items : int32[n_tiles * 256 * 4]  per tile 16 waves x 16 rows of
+ *                {row_slot | -1 (padding), nnz_begin, nnz_end, partial_slot | -1}
+ *                nnz_begin/end = the part of the row whose columns lie in the tile's column range
+ *   tile_hdr   : int32[n_tiles * 2]        {col_begin, col_end} of the tile
+ *   long_rows / partials as in wgnn_agg_fwd (every row of a column-split plan is a "long row").
+ * ------------------------------------------------------------------------- */
+int wgnn_agg_fwd_tiled(const int32_t* rowptr, const int32_t* col, const float* val,
+                       const float* alpha, int alpha_mode, int32_t self_idx,
+                       const float* h_src, const float* h_self, int64_t ld_self,
+                       const int32_t* row_ids, const float* inv_deg, const float* bias,
+                       float* out, int64_t ld_out, int64_t n_out, int32_t D, uint32_t flags,
+                       const int32_t* tile_items, const int32_t* tile_hdr, int64_t n_tiles,
+                       const int32_t* long_rows, int64_t n_long, float* partials, int64_t n_partials,
+                       void* stream);
+
+/* ---------------------------------------------------------------------------
  * K2  backward w.r.t. the source rows (autograd of K1, train.py:84):
  *     runs over the TRANSPOSED structure (row s lists the destinations r that s feeds,
  *     t_val = the same normalised weights re-ordered).

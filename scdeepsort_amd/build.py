@@ -12,7 +12,7 @@ from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
-SRC = [PKG / "csrc" / "wgnn_kernels.hip"]
+SRC = [PKG / "csrc" / "wgnn_kernels.hip", PKG / "csrc" / "wgnn_tiled.hip"]
 LIB = PKG / "libwgnn_hip.so"
 
 

@@ -91,6 +91,7 @@ class AggCsr:
     plan: Plan
     rowptr_host: np.ndarray
     _t: Optional["AggCsr"] = field(default=None, repr=False)
+    _tile_plan: Optional[object] = field(default=None, repr=False)
 
     @property
     def nnz(self) -> int:
@@ -117,6 +118,12 @@ class AggCsr:
             self._t = AggCsr(t_rowptr32, t_col, t_val, torch.empty(0, device=dev), self.n_cols, self.n_rows,
                              build_plan(host, self.plan.chunk, device=dev), host)
         return self._t
+
+    def tile_plan(self):
+        """Lazily built plan for the LDS-streamed kernel (heuristic tile geometry, see build_tile_plan)."""
+        if self._tile_plan is None:
+            self._tile_plan = build_tile_plan(self, *auto_tile_geometry(self.n_rows, self.n_cols))
+        return self._tile_plan
 
     def subplan(self, row_ids: torch.Tensor) -> Tuple[torch.Tensor, Plan]:
         """Plan restricted to a seed subset (one NodeFlow batch, train.py:71-81).  Not cached: the id
@@ -224,3 +231,103 @@ class CellGeneGraph:
             for t in (d.rowptr, d.col, d.val, d.inv_deg, d.plan.items, d.plan.long_rows):
                 tot += t.numel() * t.element_size()
         return tot
+
+
+# ------------------------------------------------------------------------------------------------
+# tile plans for the LDS-streamed kernel (wgnn_agg_fwd_tiled)
+# ------------------------------------------------------------------------------------------------
+TILE_ROWS = 256          # 16 waves x 16 rows (kTW x kRPW in csrc/wgnn_tiled.hip)
+TILE_WAVES = 16
+
+
+@dataclass
+class TilePlan:
+    items: torch.Tensor        # int32 [n_tiles, 256, 4]
+    hdr: torch.Tensor          # int32 [n_tiles, 2]
+    long_rows: torch.Tensor    # int32 [n_long, 4]
+    n_partials: int
+    n_row_tiles: int
+    n_col_splits: int
+
+    @property
+    def n_tiles(self) -> int:
+        return self.items.shape[0]
+
+
+def _snake(p: torch.Tensor, n: int) -> torch.Tensor:
+    """Boustrophedon dealing: position p of a descending-sorted list -> bin, so that bins get balanced sums."""
+    r, q = p // n, p % n
+    return torch.where(r % 2 == 0, q, n - 1 - q)
+
+
+def auto_tile_geometry(n_rows: int, n_cols: int, n_cus: int = 256) -> Tuple[int, int]:
+    """(n_row_tiles, n_col_splits): a whole number of rounds over the CUs; few-row operands (the gene side)
+    are split along the source axis so that hub rows spread over several workgroups."""
+    min_tiles = -(-n_rows // TILE_ROWS)
+    if min_tiles >= n_cus:
+        return -(-min_tiles // n_cus) * n_cus, 1
+    n_row_tiles = -(-n_rows // 250)
+    splits = max(1, min(round(5 * n_cus / n_row_tiles), n_cols // 512 or 1))
+    return n_row_tiles, splits
+
+
+def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits: int = 1,
+                    n_cus: int = 256) -> TilePlan:
+    """Group the rows of ``csr`` into tiles of <= 256 rows (nnz-balanced across tiles and across the 16
+    waves of a tile) and optionally split the column (source) range so hub rows spread over several
+    workgroups.  Pure index arithmetic on the device; runs once per graph."""
+    dev = csr.device
+    R, S = csr.n_rows, csr.n_cols
+    min_tiles = -(-R // TILE_ROWS)
+    if n_row_tiles is None:
+        per = max(1, n_cus // max(1, n_col_splits))
+        n_row_tiles = -(-min_tiles // per) * per                 # whole number of rounds over the CUs
+    n_row_tiles = max(n_row_tiles, min_tiles)
+    nnz = (csr.rowptr[1:] - csr.rowptr[:-1]).long()
+    order = torch.sort(nnz, descending=True, stable=True).indices          # row ids, longest first
+    p = torch.arange(R, device=dev)
+    tile = _snake(p, n_row_tiles)
+    rnd = p // n_row_tiles                                                  # local index inside the tile (desc. nnz)
+    if int(rnd.max()) >= TILE_ROWS:
+        raise ValueError("tile overflow")
+    wave = _snake(rnd, TILE_WAVES)
+    slot_in_wave = rnd // TILE_WAVES
+    local = wave * (TILE_ROWS // TILE_WAVES) + slot_in_wave
+    # column splits on 64-row block boundaries
+    blk = 64
+    per_split = -(-(-(-S // blk)) // n_col_splits) * blk
+    bounds = torch.arange(n_col_splits + 1, device=dev, dtype=torch.int64) * per_split
+    bounds[-1] = S
+    bounds = bounds.clamp(max=S)
+    items = torch.full((n_col_splits, n_row_tiles, TILE_ROWS, 4), -1, dtype=torch.int32, device=dev)
+    items[..., 1:3] = 0
+    rp = csr.rowptr.long()
+    if n_col_splits == 1:
+        seg_b = rp[:-1][order].unsqueeze(0)
+        seg_e = rp[1:][order].unsqueeze(0)
+    else:
+        # first nnz of every row whose column >= bound: rows are sorted by column, so row*S + col is globally sorted
+        rows_of = torch.repeat_interleave(torch.arange(R, device=dev), nnz)
+        keys = rows_of * S + csr.col.long()
+        q = (order.unsqueeze(0) * S + bounds.unsqueeze(1))                   # [splits+1, R]
+        cut = torch.searchsorted(keys, q.reshape(-1)).reshape(n_col_splits + 1, R)
+        del keys, rows_of
+        seg_b, seg_e = cut[:-1], cut[1:]
+    for k in range(n_col_splits):
+        items[k, tile, local, 0] = order.to(torch.int32)
+        items[k, tile, local, 1] = seg_b[k].to(torch.int32)
+        items[k, tile, local, 2] = seg_e[k].to(torch.int32)
+        if n_col_splits > 1:
+            items[k, tile, local, 3] = (order * n_col_splits + k).to(torch.int32)
+    hdr = torch.empty((n_col_splits, n_row_tiles, 2), dtype=torch.int32, device=dev)
+    hdr[..., 0] = bounds[:-1].to(torch.int32).unsqueeze(1)
+    hdr[..., 1] = bounds[1:].to(torch.int32).unsqueeze(1)
+    if n_col_splits > 1:
+        ar = torch.arange(R, device=dev, dtype=torch.int32)
+        long_rows = torch.stack([ar, ar * n_col_splits, torch.full_like(ar, n_col_splits), torch.zeros_like(ar)], 1).contiguous()
+        n_part = R * n_col_splits
+    else:
+        long_rows = torch.empty((0, 4), dtype=torch.int32, device=dev)
+        n_part = 0
+    return TilePlan(items.reshape(-1, TILE_ROWS, 4).contiguous(), hdr.reshape(-1, 2).contiguous(), long_rows, n_part,
+                    n_row_tiles, n_col_splits)

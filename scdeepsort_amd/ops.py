@@ -48,6 +48,9 @@ def _dtype_code(t: torch.Tensor) -> int:
 # Optional launch-level timing hook (bench.py): when set to a list, every K1 call appends
 # (tag, start_event, end_event) recorded on the stream the kernels are enqueued on.
 PROFILE = None
+DEBUG_FLAGS = 0      # ablation switches of the tiled kernel (timing experiments only)
+# K1 dispatch: passes with nnz*D above this go to the LDS-streamed kernel (None = always row-wave)
+TILED_MIN_WORK = 2_000_000_000
 
 
 def _partials(plan: Plan, D: int, device) -> Optional[torch.Tensor]:
@@ -65,6 +68,10 @@ def agg_fwd(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, self_idx: int
     D = h_src.shape[1]
     if D % 4:
         raise WgnnError(f"feature width {D} must be a multiple of 4")
+    if (TILED_MIN_WORK is not None and row_ids is None and out is None and h_src.dtype == torch.float32
+            and (out_dtype in (None, torch.float32)) and D <= 256 and csr.nnz * D >= TILED_MIN_WORK):
+        return agg_fwd_tiled(csr, csr.tile_plan(), alpha, mode, self_idx, h_src, h_self, bias=bias, relu=relu,
+                             no_mean=no_mean)
     if h_self is not None:
         h_self = _rowmajor(h_self)
         if h_self.dtype != h_src.dtype or h_self.shape[1] != D:
@@ -77,6 +84,8 @@ def agg_fwd(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, self_idx: int
     out_dtype = out_dtype or h_src.dtype
     if out is None:
         out = torch.empty((n_out, D), dtype=out_dtype, device=dev)
+    if n_out == 0:
+        return out
     flags = (_lib.FLAG_RELU if relu else 0) | (_lib.FLAG_NO_MEAN if no_mean else 0) | \
             (_lib.FLAG_NO_SELF if h_self is None else 0) | (_lib.FLAG_SELF_COMPACT if self_compact else 0)
     if alpha is not None:
@@ -157,6 +166,45 @@ def agg_bwd_alpha(csr: AggCsr, g: torch.Tensor, h_src: torch.Tensor, h_self: Opt
         _ptr(part), plan.n_partials, _stream(dev))
     _lib.check(rc, "wgnn_agg_bwd_alpha")
     return d_row, d_self
+
+
+def agg_fwd_tiled(csr: AggCsr, tplan, alpha: Optional[torch.Tensor], mode: int, self_idx: int,
+                  h_src: torch.Tensor, h_self: Optional[torch.Tensor], *, bias: Optional[torch.Tensor] = None,
+                  relu: bool = False, no_mean: bool = False) -> torch.Tensor:
+    """K1t ``wgnn_agg_fwd_tiled``: same result as :func:`agg_fwd`, source table streamed through LDS."""
+    dev = _require_cuda(h_src, h_self, alpha, bias, csr.col)
+    if h_src.dtype != torch.float32:
+        raise WgnnError("tiled kernel is f32 only")
+    h_src = h_src.contiguous()
+    D = h_src.shape[1]
+    if h_self is not None:
+        h_self = _rowmajor(h_self)
+    out = torch.empty((csr.n_rows, D), dtype=torch.float32, device=dev)
+    flags = (_lib.FLAG_RELU if relu else 0) | (_lib.FLAG_NO_MEAN if no_mean else 0) | \
+            (_lib.FLAG_NO_SELF if h_self is None else 0) | DEBUG_FLAGS
+    if alpha is not None:
+        alpha = alpha.reshape(-1)
+        if alpha.dtype != torch.float32 or not alpha.is_contiguous():
+            alpha = alpha.float().contiguous()
+    if bias is not None:
+        bias = bias.float().contiguous()
+    part = torch.empty(tplan.n_partials * D, dtype=torch.float32, device=dev) if tplan.n_partials else None
+    ev = None
+    if PROFILE is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record(torch.cuda.current_stream(dev))
+    n_long = tplan.long_rows.shape[0]
+    rc = _lib.lib().wgnn_agg_fwd_tiled(
+        _ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), _ptr(alpha), mode, self_idx,
+        _ptr(h_src), _ptr(h_self), h_self.stride(0) if h_self is not None else 0,
+        None, _ptr(csr.inv_deg), _ptr(bias), _ptr(out), out.stride(0), csr.n_rows, D, flags,
+        _ptr(tplan.items), _ptr(tplan.hdr), tplan.n_tiles,
+        _ptr(tplan.long_rows) if n_long else None, n_long, _ptr(part), tplan.n_partials, _stream(dev))
+    _lib.check(rc, "wgnn_agg_fwd_tiled")
+    if ev is not None:
+        ev[1].record(torch.cuda.current_stream(dev))
+        PROFILE.append((("rows", csr.n_rows, "cols", csr.n_cols, "nnz", csr.nnz, "D", D, "mode", mode), ev[0], ev[1]))
+    return out
 
 
 class WeightedMeanAggregate(torch.autograd.Function):
