@@ -115,19 +115,24 @@ int wgnn_agg_fwd(const int32_t* rowptr, const int32_t* col, const float* val,
 /* ---------------------------------------------------------------------------
  * K1t forward, LDS-streamed variant of K1 (same arithmetic, same outputs) for D <= 256, f32,
  *     h_src contiguous (leading dimension == D).  One 1024-thread workgroup per TILE of up to 256
- *     destination rows; the source table is streamed through LDS in 64-row blocks.
+ *     destination rows (16 waves x 16 rows); the source table is streamed through LDS in 64-row
+ *     blocks.  The tile plan is a re-ordering of the CSR (built once per graph):
  *
- *   tile_items : int32[n_tiles * 256 * 4]  per tile 16 waves x 16 rows of
- *                {row_slot | -1 (padding), nnz_begin, nnz_end, partial_slot | -1}
- *                nnz_begin/end = the part of the row whose columns lie in the tile's column range
- *   tile_hdr   : int32[n_tiles * 2]        {col_begin, col_end} of the tile
+ *   tile_hdr   : int32[n_tiles * 2]        {col_begin, col_end} = source range the tile reduces over
+ *   tile_items : int32[n_tiles * 256 * 4]  per tile, wave-major: {row_slot | -1 (padding), -, -, partial_slot | -1}
+ *   entries    : int32[nnz * 2]            {dst_slot_in_wave << 8 | src_row_in_block, weight (f32 bits)}
+ *                                          sorted by (tile, block, wave, dst_slot); block = (col-col_begin)/64
+ *   seg_ptr    : int32[n_tiles*nblk_max*16 + 1]  entry offsets per (tile, block, wave)
  *   long_rows / partials as in wgnn_agg_fwd (every row of a column-split plan is a "long row").
+ *   src_scratch: float[n_src * D], required for WGNN_SRC_IS_GENE: alpha is folded into the source rows
+ *                once ((h*alpha), gnn.py:54) instead of once per edge.
  * ------------------------------------------------------------------------- */
-int wgnn_agg_fwd_tiled(const int32_t* rowptr, const int32_t* col, const float* val,
-                       const float* alpha, int alpha_mode, int32_t self_idx,
-                       const float* h_src, const float* h_self, int64_t ld_self,
+int wgnn_agg_fwd_tiled(const int32_t* rowptr, const float* alpha, int alpha_mode, int32_t self_idx,
+                       const float* h_src, int64_t n_src, float* src_scratch,
+                       const float* h_self, int64_t ld_self,
                        const int32_t* row_ids, const float* inv_deg, const float* bias,
                        float* out, int64_t ld_out, int64_t n_out, int32_t D, uint32_t flags,
+                       const int32_t* entries, const int32_t* seg_ptr, int32_t nblk_max,
                        const int32_t* tile_items, const int32_t* tile_hdr, int64_t n_tiles,
                        const int32_t* long_rows, int64_t n_long, float* partials, int64_t n_partials,
                        void* stream);

@@ -34,7 +34,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not needs_build():
         return LIB
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-pass-failed", f"-I{ROOT / 'include'}", *map(str, SRC), "-o", str(LIB)]
+           "-Wno-pass-failed", "-Wno-inline-asm", f"-I{ROOT / 'include'}", *map(str, SRC), "-o", str(LIB)]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -248,6 +248,9 @@ class TilePlan:
     n_partials: int
     n_row_tiles: int
     n_col_splits: int
+    entries: Optional[torch.Tensor] = None     # int32 [nnz, 2]  {dst_slot<<8 | src_local, weight bits}
+    seg_ptr: Optional[torch.Tensor] = None     # int32 [n_tiles*nblk_max*16 + 1]
+    nblk_max: int = 0
 
     @property
     def n_tiles(self) -> int:
@@ -329,5 +332,28 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
     else:
         long_rows = torch.empty((0, 4), dtype=torch.int32, device=dev)
         n_part = 0
+    # ---- entries: the CSR re-ordered by (tile, block, wave, destination slot)
+    tile_r = torch.empty(R, dtype=torch.int64, device=dev); tile_r[order] = tile
+    wave_r = torch.empty(R, dtype=torch.int64, device=dev); wave_r[order] = wave
+    slot_r = torch.empty(R, dtype=torch.int64, device=dev); slot_r[order] = slot_in_wave
+    nblk_max = max(1, per_split // blk)
+    rows_of = torch.repeat_interleave(torch.arange(R, device=dev), nnz)
+    colv = csr.col.long()
+    ksplit = torch.div(colv, per_split, rounding_mode="floor")
+    rel = colv - ksplit * per_split
+    key = ((ksplit * n_row_tiles + tile_r[rows_of]) * nblk_max + torch.div(rel, blk, rounding_mode="floor")) * TILE_WAVES \
+        + wave_r[rows_of]
+    meta = ((slot_r[rows_of] << 8) | (rel % blk)).to(torch.int32)
+    del ksplit, rel, colv
+    key = key * (TILE_ROWS // TILE_WAVES) + slot_r[rows_of]
+    del rows_of
+    perm = torch.sort(key, stable=True).indices
+    n_seg = n_col_splits * n_row_tiles * nblk_max * TILE_WAVES
+    counts = torch.bincount(torch.div(key, TILE_ROWS // TILE_WAVES, rounding_mode="floor"), minlength=n_seg)
+    del key
+    seg_ptr = torch.zeros(n_seg + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, out=seg_ptr[1:])
+    entries = torch.stack([meta[perm], csr.val.view(torch.int32)[perm]], 1).contiguous()
+    del perm, meta
     return TilePlan(items.reshape(-1, TILE_ROWS, 4).contiguous(), hdr.reshape(-1, 2).contiguous(), long_rows, n_part,
-                    n_row_tiles, n_col_splits)
+                    n_row_tiles, n_col_splits, entries, seg_ptr.to(torch.int32), nblk_max)

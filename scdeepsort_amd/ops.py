@@ -194,11 +194,12 @@ def agg_fwd_tiled(csr: AggCsr, tplan, alpha: Optional[torch.Tensor], mode: int, 
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record(torch.cuda.current_stream(dev))
     n_long = tplan.long_rows.shape[0]
+    scratch = torch.empty_like(h_src) if mode == SRC_IS_GENE else None
     rc = _lib.lib().wgnn_agg_fwd_tiled(
-        _ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), _ptr(alpha), mode, self_idx,
-        _ptr(h_src), _ptr(h_self), h_self.stride(0) if h_self is not None else 0,
+        _ptr(csr.rowptr), _ptr(alpha), mode, self_idx,
+        _ptr(h_src), h_src.shape[0], _ptr(scratch), _ptr(h_self), h_self.stride(0) if h_self is not None else 0,
         None, _ptr(csr.inv_deg), _ptr(bias), _ptr(out), out.stride(0), csr.n_rows, D, flags,
-        _ptr(tplan.items), _ptr(tplan.hdr), tplan.n_tiles,
+        _ptr(tplan.entries), _ptr(tplan.seg_ptr), tplan.nblk_max, _ptr(tplan.items), _ptr(tplan.hdr), tplan.n_tiles,
         _ptr(tplan.long_rows) if n_long else None, n_long, _ptr(part), tplan.n_partials, _stream(dev))
     _lib.check(rc, "wgnn_agg_fwd_tiled")
     if ev is not None:

@@ -16,6 +16,7 @@ def timeit(f,n=5):
     f(); torch.cuda.synchronize(); t=time.perf_counter()
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.perf_counter()-t)/n*1e3
+ops.TILED_MIN_WORK=None
 ref_c=sda.agg_fwd(g.cg,alpha,sda.SRC_IS_GENE,G+1,hg,hc,bias=bias,relu=True)
 ref_g=sda.agg_fwd(g.gc,alpha,sda.DST_IS_GENE,G,hc,hg,bias=bias,relu=True)
 print('v1 cells ms',timeit(lambda: sda.agg_fwd(g.cg,alpha,sda.SRC_IS_GENE,G+1,hg,hc,bias=bias,relu=True)),
