@@ -121,22 +121,25 @@ __global__ void __launch_bounds__(kTW * 64) agg_tiled(const KArgs a, const TArgs
     auto block = [&](int b, int& cs, int& ce0, const int2& cur0, const int2& cur1, int ns, int ne, int2& nxt0, int2& nxt1) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my DMA pieces of block b and my entry chunks have landed
         __syncthreads();                                      // everyone's have; everyone is done with block b-1
+        // (ns, ne) were fetched with scalar loads at the END of the previous block; retire them here so that no SMEM
+        // is outstanding during the FMA loop (a pending SMEM forces every LDS wait to lgkmcnt(0))
+        asm volatile("" ::"s"(ns), "s"(ne));
         if (b + 1 < nblk) {
-            load_chunk(ns, ne, nxt0);                         // (ns, ne) were fetched a block ago
+            load_chunk(ns, ne, nxt0);
             load_chunk(ns + 64, ne, nxt1);
             if (do_fill) fill(b + 1, (b + 1) & 1);            // DMA of the next block overlaps this block's FMAs
         }
-        const int cs_ = cs, ce_ = ce0;                        // this block's segment (copied: cs/ce0 are reloaded below)
-        if (b + 2 < nblk) { cs = seg[(b + 2) * kTW]; ce0 = seg[(b + 2) * kTW + 1]; }
-        if (!do_comp) return;
+        const int cs_ = cs, ce_ = ce0;                        // this block's segment
         const char* lbuf = smem + (b & 1) * buf_bytes + lane * 16;
         int q = 0;
-        for (int s = cs_; s < ce_ || q == 0; s += 64, ++q) {   // usually one chunk; > 128 entries per wave-block is rare
+        for (int s = cs_; (s < ce_ || q == 0) && do_comp; s += 64, ++q) {   // usually one chunk; > 128 per wave-block is rare
             int2 ent = cur0;
             if (q == 1) ent = cur1;
             if (q >= 2) load_chunk(s, ce_, ent);
             consume(ent, lbuf);
         }
+        asm volatile("" ::: "memory");
+        if (b + 2 < nblk) { cs = seg[(b + 2) * kTW]; ce0 = seg[(b + 2) * kTW + 1]; }   // block b+2's segment, used in block b+1
     };
 
     if (nblk > 0) {
@@ -169,30 +172,48 @@ __global__ void __launch_bounds__(kTW * 64) agg_tiled(const KArgs a, const TArgs
 }
 
 // ---------------------------------------------------------------------------------------------
-// D == 256 specialisation: FLAT entry loop.  The 16 x float4 accumulators of a wave are pinned to
-// v[64:127] and updated through GPR-index mode (s_set_gpr_idx_on: VGPR number += M0[7:0]) so the
-// destination row of an entry can be a run-time value: no per-row control flow, every entry costs
-// 2 v_readlane + 1 ds_read_b128 + 2 v_pk_fma_f32, and LDS waits are static counts.
+// D == 256 specialisation: FLAT entry loop with a hand-scheduled pipeline.
+//  * Register file split: the compiler may allocate v[0:47] only (amdgpu_num_vgpr(48)); v[48:63] are two
+//    LDS staging buffers (XA, XB: two float4 each) and v[64:127] the wave's 16 x float4 accumulators.
+//    Those 80 registers are touched exclusively by literal-register inline asm, so the compiler never
+//    copies or spills them.
+//  * The destination row of an entry is a run-time value: the accumulators are addressed through GPR-index
+//    mode (s_set_gpr_idx_on: VGPR number += M0[7:0]), so there is no per-row control flow - an entry costs
+//    2 v_readlane + 1 v_add + 1 ds_read_b128 + 2 v_pk_fma_f32.
+//  * Entries are consumed in pairs through a two-stage pipeline: pair g+1's LDS reads are in flight while pair
+//    g's FMAs issue; every wait is a static count.
 // ---------------------------------------------------------------------------------------------
-typedef float f32x32 __attribute__((ext_vector_type(32)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct Sc2 { int r0, r1; unsigned long long w0, w1; };     // per-entry scalars: pk (low byte = 4*slot), weight
+struct Ad2 { int a0, a1; };                                // per-lane LDS byte addresses of a pair
 
-#define WGNN_FMA_IDX(R4_, W_, X_)                                                                \
-    do {                                                                                         \
-        const float4 xx_ = (X_);                                                                 \
-        const f32x2 lo_ = {xx_.x, xx_.y}, hi_ = {xx_.z, xx_.w};                                  \
-        const unsigned long long ww_ = (unsigned)(W_);                                           \
-        asm volatile("s_set_gpr_idx_on %[ri], gpr_idx(SRC2,DST)\n\t"                            \
-                     "v_pk_fma_f32 v[64:65], %[ww], %[lo], v[64:65] op_sel_hi:[0,1,1]\n\t"       \
-                     "v_pk_fma_f32 v[66:67], %[ww], %[hi], v[66:67] op_sel_hi:[0,1,1]\n\t"       \
-                     "s_set_gpr_idx_off"                                                         \
-                     : "+{v[64:95]}"(accA), "+{v[96:127]}"(accB)                                 \
-                     : [ri] "s"(R4_), [ww] "s"(ww_), [lo] "v"(lo_), [hi] "v"(hi_)                \
-                     : "m0");                                                                    \
-    } while (0)
+#define WGNN_FMA2_TXT(X0, X1, X2, X3)                                                             \
+    "s_set_gpr_idx_on %[r0], gpr_idx(SRC2,DST)\n\t"                                              \
+    "v_pk_fma_f32 v[64:65], %[w0], v[" #X0 "], v[64:65] op_sel_hi:[0,1,1]\n\t"                    \
+    "v_pk_fma_f32 v[66:67], %[w0], v[" #X1 "], v[66:67] op_sel_hi:[0,1,1]\n\t"                    \
+    "s_set_gpr_idx_idx %[r1]\n\t"                                                                 \
+    "v_pk_fma_f32 v[64:65], %[w1], v[" #X2 "], v[64:65] op_sel_hi:[0,1,1]\n\t"                    \
+    "v_pk_fma_f32 v[66:67], %[w1], v[" #X3 "], v[66:67] op_sel_hi:[0,1,1]\n\t"                    \
+    "s_set_gpr_idx_off"
+#define WGNN_FMA2_A WGNN_FMA2_TXT(48:49, 50:51, 52:53, 54:55)
+#define WGNN_FMA2_B WGNN_FMA2_TXT(56:57, 58:59, 60:61, 62:63)
+#define WGNN_SC_IN(S_) [r0] "s"(S_.r0), [r1] "s"(S_.r1), [w0] "s"(S_.w0), [w1] "s"(S_.w1)
+#define WGNN_AD_IN(A_) [a0] "v"(A_.a0), [a1] "v"(A_.a1)
+#define WGNN_CLOB "m0", "memory", "v48", "v63", "v64", "v127"
+
+#define WGNN_PRIME_A(AD_)                                                                         \
+    asm volatile("ds_read_b128 v[48:51], %[a0]\n\tds_read_b128 v[52:55], %[a1]" ::WGNN_AD_IN(AD_) : WGNN_CLOB)
+#define WGNN_STEP_AB(SC_, AD_)     /* current = XA, next pair's reads -> XB */                    \
+    asm volatile("ds_read_b128 v[56:59], %[a0]\n\tds_read_b128 v[60:63], %[a1]\n\t"               \
+                 "s_waitcnt lgkmcnt(2)\n\t" WGNN_FMA2_A ::WGNN_SC_IN(SC_), WGNN_AD_IN(AD_) : WGNN_CLOB)
+#define WGNN_STEP_BA(SC_, AD_)     /* current = XB, next pair's reads -> XA */                    \
+    asm volatile("ds_read_b128 v[48:51], %[a0]\n\tds_read_b128 v[52:55], %[a1]\n\t"               \
+                 "s_waitcnt lgkmcnt(2)\n\t" WGNN_FMA2_B ::WGNN_SC_IN(SC_), WGNN_AD_IN(AD_) : WGNN_CLOB)
+#define WGNN_LAST_A(SC_) asm volatile("s_waitcnt lgkmcnt(0)\n\t" WGNN_FMA2_A ::WGNN_SC_IN(SC_) : WGNN_CLOB)
+#define WGNN_DRAIN() asm volatile("s_waitcnt lgkmcnt(0)" ::: WGNN_CLOB)
 
 template <typename TOut, int EPI>
-__global__ void __launch_bounds__(kTW * 64) agg_tiled_flat(const KArgs a, const TArgs t) {
+__global__ void __launch_bounds__(kTW * 64) __attribute__((amdgpu_num_vgpr(48)))
+agg_tiled_flat(const KArgs a, const TArgs t) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int row_bytes = 1024, buf_bytes = kKB * row_bytes;
     const int lane = threadIdx.x & 63;
@@ -204,7 +225,9 @@ __global__ void __launch_bounds__(kTW * 64) agg_tiled_flat(const KArgs a, const 
     cptr_t seg = (cptr_t)(t.seg_ptr + ((size_t)tile * t.nblk_max) * kTW + wave);
     const bool do_fill = !(a.flags & kDbgNoFill), do_comp = !(a.flags & kDbgNoCompute);
 
-    f32x32 accA = 0.f, accB = 0.f;                   // rows 0..7 -> v[64:95], rows 8..15 -> v[96:127]
+    for (int r = 0; r < kRPW; ++r)                       // zero the accumulators v[64:127]
+        asm volatile("s_set_gpr_idx_on %0, gpr_idx(DST)\n\tv_mov_b32 v64, 0\n\tv_mov_b32 v65, 0\n\t"
+                     "v_mov_b32 v66, 0\n\tv_mov_b32 v67, 0\n\ts_set_gpr_idx_off" ::"s"(r * 4) : WGNN_CLOB);
 
     auto fill = [&](int b, int buf) {
         const int r0 = cb + b * kKB;
@@ -214,80 +237,82 @@ __global__ void __launch_bounds__(kTW * 64) agg_tiled_flat(const KArgs a, const 
         for (int p = wave; p * 1024 < nbytes; p += kTW)
             __builtin_amdgcn_global_load_lds((gptr_t)(g + p * 1024 + lane * 16), (lptr_t)(l + p * 1024), 16, 0, 0);
     };
+    // lane j <- entry s+j; lanes past the segment end replicate its LAST entry with weight 0, so a chunk can always
+    // be processed in whole pairs (the padding adds 0 * x of a source row the destination already uses)
     auto load_chunk = [&](int s, int e, int2& ent) {
-        const int idx = s + lane;
         ent = make_int2(0, 0);
-        if (idx < e) ent = t.entries[idx];
+        if (s < e) {
+            const int idx = s + lane;
+            ent = t.entries[min(idx, e - 1)];
+            if (idx >= e) ent.y = 0;
+        }
     };
     // n (<= 64) entries of one chunk; meta = dst_slot<<8 | src_local
     auto consume = [&](const int2& ent, int n, const char* lbuf) {
-        const int pk = ((ent.x >> 8) << 18) | ((ent.x & 0xFF) << 10);      // (4*slot)<<16 | src_local*1024
-        int j = 0;
-        for (; j + 3 < n; j += 4) {
-            const int m0 = __builtin_amdgcn_readlane(pk, j), m1 = __builtin_amdgcn_readlane(pk, j + 1);
-            const int m2 = __builtin_amdgcn_readlane(pk, j + 2), m3 = __builtin_amdgcn_readlane(pk, j + 3);
-            const float4 x0 = *reinterpret_cast<const float4*>(lbuf + (m0 & 0xFFFF));
-            const float4 x1 = *reinterpret_cast<const float4*>(lbuf + (m1 & 0xFFFF));
-            const float4 x2 = *reinterpret_cast<const float4*>(lbuf + (m2 & 0xFFFF));
-            const float4 x3 = *reinterpret_cast<const float4*>(lbuf + (m3 & 0xFFFF));
-            const int w0 = __builtin_amdgcn_readlane(ent.y, j), w1 = __builtin_amdgcn_readlane(ent.y, j + 1);
-            const int w2 = __builtin_amdgcn_readlane(ent.y, j + 2), w3 = __builtin_amdgcn_readlane(ent.y, j + 3);
-            WGNN_FMA_IDX(m0 >> 16, w0, x0);
-            WGNN_FMA_IDX(m1 >> 16, w1, x1);
-            WGNN_FMA_IDX(m2 >> 16, w2, x2);
-            WGNN_FMA_IDX(m3 >> 16, w3, x3);
-        }
-        for (; j < n; ++j) {
-            const int m0 = __builtin_amdgcn_readlane(pk, j);
-            const float4 x0 = *reinterpret_cast<const float4*>(lbuf + (m0 & 0xFFFF));
-            const int w0 = __builtin_amdgcn_readlane(ent.y, j);
-            WGNN_FMA_IDX(m0 >> 16, w0, x0);
+        const int pk = ((ent.x & 0xFF) << 18) | ((ent.x >> 8) << 2);       // (src_local*1024)<<8 | 4*slot
+        const int lbase = (int)(size_t)lbuf;                               // LDS byte address of this lane's slice
+        auto scal = [&](int j, Sc2& c, Ad2& ad) {
+            c.r0 = __builtin_amdgcn_readlane(pk, j); c.r1 = __builtin_amdgcn_readlane(pk, j + 1);
+            c.w0 = (unsigned)__builtin_amdgcn_readlane(ent.y, j); c.w1 = (unsigned)__builtin_amdgcn_readlane(ent.y, j + 1);
+            ad.a0 = lbase + (int)((unsigned)c.r0 >> 8); ad.a1 = lbase + (int)((unsigned)c.r1 >> 8);
+        };
+        const int ng = (n + 1) >> 1;                      // padded to whole pairs: see load_chunk
+        if (ng > 0) {
+            Sc2 cA, cB; Ad2 dA, dB;
+            scal(0, cA, dA);
+            WGNN_PRIME_A(dA);
+            int g = 0;
+            for (; g + 2 <= ng; g += 2) {                 // invariant: XA holds (in flight) pair g, cA its scalars
+                scal(2 * g + 2, cB, dB);
+                WGNN_STEP_AB(cA, dB);
+                scal(2 * g + 4, cA, dA);                  // may run past n (padding lanes): harmless reads
+                WGNN_STEP_BA(cB, dA);
+            }
+            if (g < ng) { WGNN_LAST_A(cA); } else { WGNN_DRAIN(); }         // retire the look-ahead reads
         }
     };
-    auto block = [&](int b, int& cs, int& ce0, const int2& cur0, const int2& cur1, int ns, int ne, int2& nxt0, int2& nxt1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+    auto block = [&](int b, int& cs, int& ce0, const int2& cur0, int ns, int ne, int2& nxt0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my DMA pieces of block b and my entry chunk have landed
+        __syncthreads();                                      // everyone's have; everyone is done with block b-1
+        asm volatile("" ::"s"(ns), "s"(ne));                  // retire the scalar loads issued at the end of block b-1
         if (b + 1 < nblk) {
-            load_chunk(ns, ne, nxt0);                         // (ns, ne) were fetched a block ago
-            load_chunk(ns + 64, ne, nxt1);
+            load_chunk(ns, ne, nxt0);
             if (do_fill) fill(b + 1, (b + 1) & 1);
         }
         const int cs_ = cs, ce_ = ce0;
-        if (b + 2 < nblk) { cs = seg[(b + 2) * kTW]; ce0 = seg[(b + 2) * kTW + 1]; }
-        if (!do_comp) return;
         const char* lbuf = smem + (b & 1) * buf_bytes + lane * 16;
         int q = 0;
-        for (int s = cs_; s < ce_; s += 64, ++q) {
+        for (int s = cs_; s < ce_ && do_comp; s += 64, ++q) {
             int2 ent = cur0;
-            if (q == 1) ent = cur1;
-            if (q >= 2) load_chunk(s, ce_, ent);
+            if (q >= 1) load_chunk(s, ce_, ent);              // rare: more than 64 entries for this wave in one block
             consume(ent, min(64, ce_ - s), lbuf);
         }
+        asm volatile("" ::: "memory");
+        if (b + 2 < nblk) { cs = seg[(b + 2) * kTW]; ce0 = seg[(b + 2) * kTW + 1]; }
     };
 
     if (nblk > 0) {
         int sA = seg[0], eA = seg[1], sB = 0, eB = 0;
         if (nblk > 1) { sB = seg[kTW]; eB = seg[kTW + 1]; }
-        int2 a0, a1, b0, b1;
+        int2 a0, b0;
         load_chunk(sA, eA, a0);
-        load_chunk(sA + 64, eA, a1);
-        b0 = b1 = make_int2(0, 0);
+        b0 = make_int2(0, 0);
         if (do_fill) fill(0, 0);
         for (int b = 0; b < nblk; b += 2) {
-            block(b, sA, eA, a0, a1, sB, eB, b0, b1);
-            if (b + 1 < nblk) block(b + 1, sB, eB, b0, b1, sA, eA, a0, a1);
+            block(b, sA, eA, a0, sB, eB, b0);
+            if (b + 1 < nblk) block(b + 1, sB, eB, b0, sA, eA, a0);
         }
     }
 
     const int4* __restrict__ items = t.tile_items + (size_t)tile * kTileRows + wave * kRPW;
-#pragma unroll
     for (int i = 0; i < kRPW; ++i) {
         const int4 it = items[i];
         const int slot = __builtin_amdgcn_readfirstlane(it.x), pslot = __builtin_amdgcn_readfirstlane(it.w);
         if (slot < 0) continue;
         float4 v;
-        if (i < 8) v = make_float4(accA[4 * (i & 7)], accA[4 * (i & 7) + 1], accA[4 * (i & 7) + 2], accA[4 * (i & 7) + 3]);
-        else       v = make_float4(accB[4 * (i & 7)], accB[4 * (i & 7) + 1], accB[4 * (i & 7) + 2], accB[4 * (i & 7) + 3]);
+        asm volatile("s_set_gpr_idx_on %4, gpr_idx(SRC0)\n\tv_mov_b32 %0, v64\n\tv_mov_b32 %1, v65\n\t"
+                     "v_mov_b32 %2, v66\n\tv_mov_b32 %3, v67\n\ts_set_gpr_idx_off"
+                     : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w) : "s"(i * 4) : "m0");
         if (pslot >= 0) {
             st4(a.partials + (size_t)pslot * a.D + lane * 4, v);
         } else {
