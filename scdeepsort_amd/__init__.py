@@ -8,8 +8,9 @@ operator does, and fails loudly when it is missing.
 from ._lib import WgnnError, DST_IS_GENE, NO_ALPHA, SRC_IS_GENE
 from .graph import AggCsr, CellGeneGraph, Plan, build_plan
 from .gnn import GNN, NodeUpdate
+from .api import DeepSortClassifier, DeepSortPredictor
 from .ops import agg_bwd_alpha, agg_bwd_src, agg_fwd, weighted_mean_aggregate
 
-__all__ = ["GNN", "NodeUpdate", "CellGeneGraph", "AggCsr", "Plan", "build_plan", "agg_fwd", "agg_bwd_src",
+__all__ = ["GNN", "NodeUpdate", "DeepSortClassifier", "DeepSortPredictor", "CellGeneGraph", "AggCsr", "Plan", "build_plan", "agg_fwd", "agg_bwd_src",
            "agg_bwd_alpha", "weighted_mean_aggregate", "WgnnError", "SRC_IS_GENE", "DST_IS_GENE", "NO_ALPHA"]
 __version__ = "0.1.0"

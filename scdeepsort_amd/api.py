@@ -1,0 +1,207 @@
+"""Thin counterparts of the documented ``deepsort`` package classes (reference ``docs/api.rst:6-130``), whose
+source is not in the reference tree; the tree holds the equivalent CLI classes ``Trainer`` (``train.py:16-123``)
+and ``Runner`` (``predict.py:17-152``).  Same constructor keywords, same ``fit`` / ``predict`` signatures, same
+bundle on disk (``{species}-{tissue}.pt`` = ``{'model', 'optimizer'}`` (train.py:117-123), ``{tissue}_genes.txt`` /
+``{tissue}_cell_type.txt`` written with ``\\r\\n`` (preprocess_internal.py:59-67), ``{species}_{tissue}_data.npz``
+support matrix (preprocess_internal.py:180)).
+
+Only the per-cell hot path (graph normalisation, aggregation, autograd) runs on the GPU through the HIP
+kernels; file ingest, vocabularies and PCA are ordinary host code kept deliberately small.
+"""
+from __future__ import annotations
+
+from pathlib import Path
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+import pandas as pd
+import scipy.sparse as sp
+import torch
+import torch.nn.functional as F
+
+from ._lib import WgnnError
+from .gnn import GNN
+from .graph import CellGeneGraph
+
+
+def _device(gpu_id: int) -> torch.device:
+    if not torch.cuda.is_available():
+        raise WgnnError("the MI355X path needs a GPU (gpu_id=-1 meant CPU in the reference; there is no CPU fallback here)")
+    return torch.device("cuda", max(gpu_id, 0))
+
+
+def _read_expression(path, file_type: str) -> pd.DataFrame:
+    """(genes x cells) table as produced by pre-process.R:72-74 -> DataFrame (cells x genes)."""
+    if file_type == "csv":
+        df = pd.read_csv(path, index_col=0)
+    elif file_type == "gz":
+        df = pd.read_csv(path, compression="gzip", index_col=0)
+    else:
+        raise ValueError(f"Not supported type {file_type!r}: csv or gz")
+    return df.transpose(copy=True)
+
+
+def _features(expr: sp.csr_matrix, n_support: int, dense_dim: int, seed) -> np.ndarray:
+    """gene_feat = PCA(dense_dim) of the support cells' (genes x cells) matrix; cell_feat = rownorm(X) . gene_feat
+    (preprocess_internal.py:183-202, preprocess.py:194-210)."""
+    from sklearn.decomposition import PCA
+    dense = expr.toarray().astype(np.float64)
+    k = min(dense_dim, dense.shape[1], n_support)
+    gene_feat = PCA(k, random_state=seed).fit_transform(dense[:n_support].T)
+    if k < dense_dim:
+        gene_feat = np.pad(gene_feat, ((0, 0), (0, dense_dim - k)))
+    norm = dense / (dense.sum(axis=1, keepdims=True) + 1e-6)
+    return np.concatenate([gene_feat, norm @ gene_feat]).astype(np.float32)
+
+
+def _classify(logits: torch.Tensor, unsure_rate: float) -> Tuple[np.ndarray, np.ndarray]:
+    """softmax -> 'unsure' iff max_prob < unsure_rate/num_classes, else argmax (predict.py:78-88)."""
+    prob = F.softmax(logits.float(), dim=1)
+    mx, arg = prob.max(dim=1)
+    unsure = mx < unsure_rate / logits.shape[1]
+    return torch.where(unsure, torch.full_like(arg, -1), arg).cpu().numpy(), prob.cpu().numpy()
+
+
+class DeepSortClassifier:
+    def __init__(self, species, tissue, dense_dim=400, hidden_dim=200, batch_size=256, dropout=0.1, gpu_id=-1,
+                 file_type='csv', learning_rate=0.001, weight_decay=5e-4, n_epochs=300, n_layers=1, threshold=0,
+                 num_neighbors=None, exclude_rate=0.005, random_seed=None, validation_fraction=0.1):
+        if num_neighbors not in (None, 0):
+            raise NotImplementedError("neighbour subsampling (train.py:37-40) is not built yet: all neighbours are used")
+        self.species, self.tissue = species, tissue
+        self.dense_dim, self.hidden_dim, self.batch_size, self.dropout = dense_dim, hidden_dim, batch_size, dropout
+        self.gpu_id, self.file_type = gpu_id, file_type
+        self.learning_rate, self.weight_decay, self.n_epochs, self.n_layers = learning_rate, weight_decay, n_epochs, n_layers
+        self.threshold, self.exclude_rate = threshold, exclude_rate
+        self.random_seed, self.validation_fraction = random_seed, validation_fraction
+        self.model: Optional[GNN] = None
+        self.history: List[dict] = []
+
+    # ---------------------------------------------------------------------------------------------
+    def fit(self, files: Sequence[Tuple[str, str]], save_path=None):
+        """``files`` = list of (data_file, celltype_file) (docs/api.rst:89-95)."""
+        dev = _device(self.gpu_id)
+        if self.random_seed is not None:
+            np.random.seed(self.random_seed); torch.manual_seed(self.random_seed)
+        tables, types = [], []
+        for data_file, type_file in files:
+            df = _read_expression(data_file, self.file_type)
+            ct = pd.read_csv(type_file, index_col=0)
+            ct.columns = ['cell', 'type']                                   # preprocess_internal.py:125-127
+            ct['type'] = ct['type'].map(str.strip)
+            assert ct['cell'].tolist() == df.index.tolist(), 'cell order of data and celltype files differs'
+            tables.append(df); types.append(ct['type'])
+        id2gene = sorted(set().union(*[set(map(str, t.columns)) for t in tables]))     # :26-41 union of genes
+        all_types = pd.concat(types)
+        counts = all_types.value_counts()
+        id2label = sorted(t for t, n in counts.items() if n / len(all_types) > self.exclude_rate)   # :91-96
+        gene2id = {g: i for i, g in enumerate(id2gene)}
+        label2id = {l: i for i, l in enumerate(id2label)}
+        mats, labels = [], []
+        for df, ty in zip(tables, types):
+            keep = ty.isin(label2id).to_numpy()
+            arr = df.to_numpy(dtype=np.float32)[keep]
+            cols = np.array([gene2id[str(c)] for c in df.columns])
+            r, c = np.nonzero(arr > self.threshold)                          # :158
+            mats.append(sp.csr_matrix((arr[r, c], (r, cols[c])), shape=(arr.shape[0], len(id2gene))))
+            labels += [label2id[t] for t in ty[keep]]
+        expr = sp.vstack(mats).tocsr(); expr.sort_indices()
+        C, G = expr.shape
+        feats = torch.from_numpy(_features(expr, C, self.dense_dim, self.random_seed)).to(dev)
+        graph = CellGeneGraph.from_expression(expr, device=dev)
+        y = torch.tensor(labels, dtype=torch.long, device=dev)
+        perm = np.random.permutation(C)
+        n_val = int(C * self.validation_fraction)
+        val_ids = torch.from_numpy(perm[:n_val] + G).to(dev); train_ids = torch.from_numpy(perm[n_val:] + G).to(dev)
+        model = GNN(self.dense_dim, self.hidden_dim, len(id2label), self.n_layers, G, activation=F.relu,
+                    dropout=self.dropout).to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay)   # train.py:34-35
+        best, self.history = -1.0, []
+        save_path = Path(save_path) if save_path is not None else None
+        if save_path is not None:
+            save_path.mkdir(parents=True, exist_ok=True)
+            (save_path / f"{self.tissue}_genes.txt").write_bytes("".join(g + "\r\n" for g in id2gene).encode())
+            (save_path / f"{self.tissue}_cell_type.txt").write_bytes("".join(l + "\r\n" for l in id2label).encode())
+            sp.save_npz(save_path / f"{self.species}_{self.tissue}_data", expr)
+
+        def accuracy(ids):
+            if len(ids) == 0:
+                return 1.0, 0
+            model.eval()
+            with torch.no_grad():
+                pred, _ = _classify(model(graph, feats, seeds=ids), 2.0)
+            truth = y[ids - G].cpu().numpy()
+            return float((pred == truth).mean()), int((pred < 0).sum())
+
+        for epoch in range(self.n_epochs):
+            model.train()
+            total = 0.0
+            order = train_ids[torch.randperm(len(train_ids), device=dev)]
+            for batch in torch.split(order, self.batch_size):                # train.py:71-87
+                logits = model(graph, feats, seeds=batch)
+                loss = F.cross_entropy(logits, y[batch - G], reduction='sum')     # train.py:36
+                opt.zero_grad(); loss.backward(); opt.step()
+                total += float(loss.detach())
+            tr_acc, _ = accuracy(train_ids)
+            va_acc, va_unsure = accuracy(val_ids)
+            self.history.append(dict(epoch=epoch, loss=total / max(1, len(train_ids)), train_acc=tr_acc, val_acc=va_acc))
+            if va_acc >= best:                                                # train.py:52-58
+                best = va_acc
+                if save_path is not None:
+                    torch.save({'model': model.state_dict(), 'optimizer': opt.state_dict()},
+                               save_path / f"{self.species}-{self.tissue}.pt")
+            if tr_acc == 1:                                                   # train.py:62-63
+                break
+        self.model, self._graph, self._feats, self._id2label, self._id2gene = model, graph, feats, id2label, id2gene
+        return self
+
+    # ---------------------------------------------------------------------------------------------
+    def predict(self, input_file, model_path, save_path=None, unsure_rate=2., file_type='csv') -> pd.DataFrame:
+        return _predict(self.species, self.tissue, input_file, Path(model_path), save_path, unsure_rate, file_type,
+                        self.dense_dim, self.hidden_dim, self.gpu_id, self.threshold, self.random_seed)
+
+
+class DeepSortPredictor:
+    def __init__(self, species, tissue, file_type='csv', unsure_rate=2.):
+        self.species, self.tissue, self.file_type, self.unsure_rate = species, tissue, file_type, unsure_rate
+
+    def predict(self, input_file, save_path=None, model_path='pretrained') -> pd.DataFrame:
+        """docs/api.rst:25-26 (the doc example also passes ``model_path=``, :42).  Uses the reference's fixed
+        predict-time sizes dense_dim=400, hidden_dim=200 (predict.py:170-172)."""
+        return _predict(self.species, self.tissue, input_file, Path(model_path), save_path, self.unsure_rate,
+                        self.file_type, 400, 200, -1, 0, 10086)
+
+
+def _predict(species, tissue, input_file, model_path: Path, save_path, unsure_rate, file_type, dense_dim, hidden_dim,
+             gpu_id, threshold, seed) -> pd.DataFrame:
+    dev = _device(gpu_id)
+    id2gene = [l.strip() for l in (model_path / f"{tissue}_genes.txt").read_text().splitlines() if l.strip()]
+    id2label = [l.strip() for l in (model_path / f"{tissue}_cell_type.txt").read_text().splitlines() if l.strip()]
+    support = sp.load_npz(model_path / f"{species}_{tissue}_data.npz").tocsr()           # preprocess.py:114-117
+    state = torch.load(model_path / f"{species}-{tissue}.pt", map_location=dev)['model']  # predict.py:56-59
+    n_layers = sum(1 for k in state if k.endswith("fc_neigh.weight"))
+    hidden_dim, dense_dim = state["layers.0.fc_neigh.weight"].shape
+    G = len(id2gene)
+    gene2id = {g: i for i, g in enumerate(id2gene)}
+    df = _read_expression(input_file, file_type)
+    cols = [c for c in df.columns if str(c) in gene2id]                                  # preprocess.py:160-161
+    arr = df[cols].to_numpy(dtype=np.float32)
+    cid = np.array([gene2id[str(c)] for c in cols])
+    r, c = np.nonzero(arr > threshold)
+    test = sp.csr_matrix((arr[r, c], (r, cid[c])), shape=(arr.shape[0], G))
+    expr = sp.vstack([support, test]).tocsr(); expr.sort_indices()
+    n_sup = support.shape[0]
+    mask = np.zeros(expr.shape[0], bool); mask[:n_sup] = True           # test cells: gene->cell edges only (preprocess.py:184-187)
+    feats = torch.from_numpy(_features(expr, n_sup, dense_dim, seed)).to(dev)
+    graph = CellGeneGraph.from_expression(expr, support_mask=mask, device=dev)
+    model = GNN(dense_dim, hidden_dim, len(id2label), n_layers, G, activation=F.relu, dropout=0.1).to(dev)
+    model.load_state_dict(state)
+    model.eval()
+    seeds = torch.arange(G + n_sup, G + expr.shape[0], device=dev)
+    with torch.no_grad():
+        pred, _ = _classify(model(graph, feats, seeds=seeds), unsure_rate)
+    out = pd.DataFrame({"index": df.index, "cell_type": [id2label[p] if p >= 0 else "unsure" for p in pred]})
+    if save_path is not None:
+        Path(save_path).mkdir(parents=True, exist_ok=True)
+        out.to_csv(Path(save_path) / f"{species}_{tissue}_{Path(input_file).stem}.csv", index=False)
+    return out

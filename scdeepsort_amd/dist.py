@@ -46,8 +46,9 @@ def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
-def normalise_gene_side(local_deg: torch.Tensor, local_sum: torch.Tensor, local_val_locally_normalised: torch.Tensor,
-                        row_of_nnz: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+def rescale_gene_side(local_deg: torch.Tensor, local_sum: torch.Tensor, global_deg: torch.Tensor,
+                      global_sum: torch.Tensor, local_val_locally_normalised: torch.Tensor,
+                      row_of_nnz: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """Turn per-shard normalised gene<-cell weights into globally normalised ones.
 
     Locally ``w = deg_loc * x / sum_loc`` (K4 on the shard); globally the reference needs
@@ -55,11 +56,17 @@ def normalise_gene_side(local_deg: torch.Tensor, local_sum: torch.Tensor, local_
     preprocess_internal.py:17-23), i.e. a per-gene factor ``(deg_glob/deg_loc) * (sum_loc/sum_glob)``.
     Returns (values, inv_deg_global).
     """
+    fac = torch.where(local_deg > 0, (global_deg / local_deg.clamp(min=1).float()) *
+                      (local_sum.double() / global_sum.clamp(min=1e-30)).float(), torch.zeros_like(global_deg))
+    return local_val_locally_normalised * fac[row_of_nnz.long()], 1.0 / (global_deg + 1.0)
+
+
+def normalise_gene_side(local_deg: torch.Tensor, local_sum: torch.Tensor, local_val_locally_normalised: torch.Tensor,
+                        row_of_nnz: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``rescale_gene_side`` with the global statistics obtained by two ``[G]`` all-reduces."""
     g_deg = all_reduce_sum_(local_deg.clone().float())
     g_sum = all_reduce_sum_(local_sum.clone().double())
-    fac = torch.where(local_deg > 0, (g_deg / local_deg.clamp(min=1).float()) *
-                      (local_sum.double() / g_sum.clamp(min=1e-30)).float(), torch.zeros_like(g_deg))
-    return local_val_locally_normalised * fac[row_of_nnz.long()], 1.0 / (g_deg + 1.0)
+    return rescale_gene_side(local_deg, local_sum, g_deg, g_sum, local_val_locally_normalised, row_of_nnz)
 
 
 @dataclass

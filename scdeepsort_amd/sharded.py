@@ -25,21 +25,35 @@ class ShardedWgnn:
         return self.graph.cg.nnz
 
     @staticmethod
+    def gene_stats(col: torch.Tensor, raw: torch.Tensor, num_genes: int):
+        """Per-gene (in-degree, raw weight sum) contributed by THIS shard's cells."""
+        deg = torch.bincount(col.long(), minlength=num_genes).float()
+        ssum = torch.zeros(num_genes, dtype=torch.float64, device=col.device)
+        ssum.index_add_(0, col.long(), raw.double())
+        return deg, ssum
+
+    @staticmethod
     def build(model: GNN, rowptr: torch.Tensor, col: torch.Tensor, raw: torch.Tensor, num_genes: int,
-              chunk: int = DEFAULT_CHUNK) -> "ShardedWgnn":
-        """``rowptr/col/raw``: device CSR of THIS rank's (cells x genes) raw expression."""
+              chunk: int = DEFAULT_CHUNK, global_stats=None) -> "ShardedWgnn":
+        """``rowptr/col/raw``: device CSR of THIS rank's (cells x genes) raw expression.
+        ``global_stats`` = (deg, sum) over ALL shards; when None and a process group is up they are all-reduced."""
         rank, world = D.world()
         g = CellGeneGraph.from_device_csr(rowptr, col, raw, num_genes, chunk)
-        if world > 1:
+        if world > 1 or global_stats is not None:
             # gene side: w = deg_glob * x / sum_glob over ALL ranks' cells (preprocess_internal.py:17-23)
             gc = g.gc
-            deg_loc = (gc.rowptr[1:] - gc.rowptr[:-1]).float()
+            deg_loc, sum_loc = ShardedWgnn.gene_stats(col, raw, num_genes)
+            if global_stats is None:
+                g_deg = D.all_reduce_sum_(deg_loc.clone())
+                g_sum = D.all_reduce_sum_(sum_loc.clone())
+            else:
+                g_deg, g_sum = global_stats
             row_of = torch.repeat_interleave(torch.arange(num_genes, device=col.device, dtype=torch.int32),
                                              (gc.rowptr[1:] - gc.rowptr[:-1]).long())
-            sum_loc = torch.zeros(num_genes, dtype=torch.float64, device=col.device)
-            sum_loc.index_add_(0, col.long(), raw.double())
-            gc.val, gc.inv_deg = D.normalise_gene_side(deg_loc, sum_loc, gc.val, row_of)
+            gc.val, gc.inv_deg = D.rescale_gene_side(deg_loc, sum_loc, g_deg, g_sum, gc.val, row_of)
             gc._t = None
+            gc._tile_plan = None
+            world = max(world, 2)
         return ShardedWgnn(model, g, world)
 
     # -- local arithmetic bound to the HIP kernels -------------------------------------------------

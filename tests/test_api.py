@@ -1,0 +1,85 @@
+"""DeepSortClassifier / DeepSortPredictor surface (reference docs/api.rst:6-130)."""
+import inspect
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+import scdeepsort_amd as sda
+
+
+def test_documented_signatures():
+    """Keyword names and defaults exactly as documented (docs/api.rst:12-15, 50-66, 25-26, 89-102)."""
+    sig = inspect.signature(sda.DeepSortClassifier.__init__)
+    want = dict(dense_dim=400, hidden_dim=200, batch_size=256, dropout=0.1, gpu_id=-1, file_type='csv', learning_rate=0.001,
+                weight_decay=5e-4, n_epochs=300, n_layers=1, threshold=0, num_neighbors=None, exclude_rate=0.005,
+                random_seed=None, validation_fraction=0.1)
+    got = {k: v.default for k, v in sig.parameters.items() if k not in ("self", "species", "tissue")}
+    assert got == want
+    assert list(sig.parameters)[1:3] == ["species", "tissue"]
+    p = inspect.signature(sda.DeepSortPredictor.__init__).parameters
+    assert p["file_type"].default == 'csv' and p["unsure_rate"].default == 2.
+    f = inspect.signature(sda.DeepSortClassifier.fit).parameters
+    assert list(f)[1:] == ["files", "save_path"] and f["save_path"].default is None
+    q = inspect.signature(sda.DeepSortClassifier.predict).parameters
+    assert list(q)[1:] == ["input_file", "model_path", "save_path", "unsure_rate", "file_type"]
+    assert q["unsure_rate"].default == 2. and q["file_type"].default == 'csv'
+    r = inspect.signature(sda.DeepSortPredictor.predict).parameters
+    assert list(r)[1:3] == ["input_file", "save_path"]
+
+
+def test_fails_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(sda.WgnnError):
+        sda.DeepSortClassifier("mouse", "Testis").fit([])
+
+
+def _write_dataset(tmp, name, n_cells, rng, genes, programs, with_types=True):
+    """(genes x cells) csv in the format of pre-process.R:72-74 + celltype csv (index, Cell, Cell_type)."""
+    types = rng.integers(0, len(programs), n_cells)
+    X = np.zeros((len(genes), n_cells), np.float32)
+    for j, t in enumerate(types):
+        on = rng.random(len(genes)) < (0.05 + 0.6 * programs[t])
+        X[on, j] = np.clip(rng.normal(3.0, 0.9, on.sum()), 0.5, 7.0)
+    cells = [f"{name}_C{j}" for j in range(n_cells)]
+    data = tmp / f"{name}_data.csv"
+    pd.DataFrame(X, index=genes, columns=cells).to_csv(data)
+    if not with_types:
+        return data, types
+    ct = tmp / f"{name}_celltype.csv"
+    pd.DataFrame({"Cell": cells, "Cell_type": [f"type{t} " for t in types]}).to_csv(ct)     # trailing blank: stripped like :127
+    return data, ct, types
+
+
+@pytest.mark.gpu
+def test_fit_predict_roundtrip(tmp_path):
+    rng = np.random.default_rng(0)
+    genes = [f"G{i}" for i in range(120)]
+    programs = [np.zeros(120) for _ in range(3)]
+    for t in range(3):
+        programs[t][t * 40:(t + 1) * 40] = 1.0
+    d1, c1, _ = _write_dataset(tmp_path, "mouse_Demo1", 240, rng, genes, programs)
+    d2, c2, _ = _write_dataset(tmp_path, "mouse_Demo2", 120, rng, genes, programs)
+    clf = sda.DeepSortClassifier("mouse", "Demo", dense_dim=16, hidden_dim=12, batch_size=64, n_epochs=300, n_layers=2, learning_rate=0.005,
+                                 random_seed=1, gpu_id=0, dropout=0.1)
+    clf.fit([(d1, c1), (d2, c2)], save_path=tmp_path / "bundle")
+    assert clf.history[-1]["train_acc"] > 0.95 and max(h["val_acc"] for h in clf.history) > 0.9
+    # bundle format (train.py:117-123, preprocess_internal.py:59-67,180)
+    state = torch.load(tmp_path / "bundle" / "mouse-Demo.pt", map_location="cpu")
+    assert set(state) == {"model", "optimizer"}
+    assert set(state["model"]) == {"layers.0.fc_neigh.weight", "layers.0.fc_neigh.bias", "layers.1.fc_neigh.weight",
+                                   "layers.1.fc_neigh.bias", "alpha", "linear.weight", "linear.bias"}
+    assert state["model"]["alpha"].shape == (122, 1)
+    assert (tmp_path / "bundle" / "Demo_genes.txt").read_bytes().count(b"\r\n") == 120
+    assert (tmp_path / "bundle" / "Demo_cell_type.txt").read_text().split() == ["type0", "type1", "type2"]
+    # predict on unseen cells: gene->cell edges only for them (preprocess.py:184-187)
+    dt, truth = _write_dataset(tmp_path, "mouse_Test9", 90, rng, genes, programs, with_types=False)
+    out = clf.predict(dt, model_path=tmp_path / "bundle", save_path=tmp_path / "result")
+    assert list(out.columns) == ["index", "cell_type"] and len(out) == 90
+    acc = np.mean([o == f"type{t}" for o, t in zip(out["cell_type"], truth)])
+    assert acc > 0.9
+    out2 = sda.DeepSortPredictor("mouse", "Demo").predict(dt, model_path=tmp_path / "bundle")
+    assert out2["cell_type"].tolist() == out["cell_type"].tolist()
+    assert (tmp_path / "result").exists()

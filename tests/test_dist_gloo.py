@@ -1,0 +1,97 @@
+"""World-size-2 tests of the cell-shard orchestration (scdeepsort_amd/dist.py) on CPU with gloo.
+The local arithmetic is injected (torch CPU math here, the HIP operators in production), so what is
+tested is the N>1 logic itself: shard ranges, the gene-side global normalisation, the single [G,H]
+all-reduce per forward, the logits all-gather and the SUM gradient all-reduce."""
+import os
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT)); sys.path.insert(0, str(ROOT / "tests"))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    import scipy.sparse as sp
+    from conftest import small_case
+    from oracle import wgnn_oracle as O
+    from scdeepsort_amd import dist as D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c = small_case(cells=90, genes=40, dim=12, hidden=8, n_classes=3, seed=21, test_cells=0)
+        G, C = c["G"], c["C"]
+        sd = O.init_params(12, 8, 3, 2, G, seed=3, dtype=torch.float64)
+        expr = sp.csr_matrix(c["expr"]).astype(np.float64)
+        lo, hi = D.shard_range(C, rank, world)
+        loc = expr[lo:hi]
+        # cells<-genes: per-cell normalisation is local by construction
+        nnz_c = np.diff(loc.indptr); rs = np.asarray(loc.sum(1)).ravel()
+        A_cg = loc.copy(); A_cg.data = np.repeat(nnz_c, nnz_c) * loc.data / np.repeat(rs, nnz_c)
+        inv_c = torch.from_numpy(1.0 / (nnz_c + 1.0))
+        # genes<-cells: locally normalised, then rescaled with the all-reduced statistics
+        XT = sp.csr_matrix(loc.T); XT.sort_indices()
+        deg_loc = torch.from_numpy(np.diff(XT.indptr).astype(np.float32))
+        sum_loc = torch.from_numpy(np.asarray(XT.sum(1)).ravel())
+        row_of = torch.from_numpy(np.repeat(np.arange(G), np.diff(XT.indptr)))
+        w_loc = torch.from_numpy(np.where(np.repeat(sum_loc.numpy(), np.diff(XT.indptr)) > 0,
+                                          np.repeat(deg_loc.numpy(), np.diff(XT.indptr)) * XT.data /
+                                          np.repeat(np.maximum(sum_loc.numpy(), 1e-30), np.diff(XT.indptr)), 0.0))
+        w_glob, inv_g = D.normalise_gene_side(deg_loc, sum_loc, w_loc, row_of)
+        ref = O.build_csr_graph(c["expr"], dtype=np.float64)
+        want = ref.A_gc[:, lo:hi].tocsr(); want.sort_indices()
+        np.testing.assert_allclose(w_glob.numpy(), want.data, rtol=2e-6)
+        np.testing.assert_allclose(inv_g.numpy(), 1.0 / ref.deg_g, rtol=1e-7)
+        A_gc = sp.csr_matrix((w_glob.numpy(), XT.indices, XT.indptr), shape=XT.shape)
+
+        def dense(m):
+            return torch.from_numpy(m.toarray())
+        Acg, Agc = dense(A_cg), dense(A_gc)
+        alpha = sd["alpha"].reshape(-1)
+        ops = D.LocalOps(
+            cells_layer=lambda p_g, p_c, b, relu: torch.relu(((Acg @ (alpha[:G, None] * p_g)) + alpha[G + 1] * p_c) * inv_c[:, None] + b),
+            genes_partial=lambda p_c: Agc @ p_c,
+            genes_finish=lambda part, p_g, b, relu: torch.relu((alpha[:G, None] * part + alpha[G] * p_g) * inv_g[:, None].double() + b))
+        weights = [(sd[f"layers.{i}.fc_neigh.weight"], sd[f"layers.{i}.fc_neigh.bias"]) for i in range(2)] + \
+                  [(sd["linear.weight"], sd["linear.bias"])]
+        feats = torch.from_numpy(c["feats"]).double()
+        logits = D.sharded_forward(weights, None, feats[:G], feats[G + lo:G + hi], ops, 2, gather_logits=True)
+        full = O.csr_forward(sd, ref, c["feats"].astype(np.float64), 2, dtype=np.float64)
+        np.testing.assert_allclose(logits.numpy(), full, atol=1e-6)          # every rank holds ALL cells' logits, in order
+
+        # SUM all-reduce of gradients == single-process gradient of the summed loss (train.py:36)
+        p = torch.nn.Parameter(torch.ones(5, dtype=torch.float64))
+        x = torch.arange(10, dtype=torch.float64).reshape(2, 5)
+        (p * x[rank]).sum().backward()
+        D.all_reduce_grads([p])
+        np.testing.assert_allclose(p.grad.numpy(), x.sum(0).numpy())
+        Path(out_dir, f"ok{rank}").write_text("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_sharded_forward_matches_unsharded(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_shard_ranges_partition_cells():
+    from scdeepsort_amd.dist import shard_range
+    for C in (1, 7, 100_000, 764_741):
+        for W in (1, 2, 4, 8):
+            spans = [shard_range(C, r, W) for r in range(W)]
+            assert spans[0][0] == 0 and spans[-1][1] == C
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
