@@ -237,23 +237,21 @@ agg_tiled_flat(const KArgs a, const TArgs t) {
         for (int p = wave; p * 1024 < nbytes; p += kTW)
             __builtin_amdgcn_global_load_lds((gptr_t)(g + p * 1024 + lane * 16), (lptr_t)(l + p * 1024), 16, 0, 0);
     };
-    // lane j <- entry s+j; lanes past the segment end replicate its LAST entry with weight 0, so a chunk can always
-    // be processed in whole pairs (the padding adds 0 * x of a source row the destination already uses)
+    // lane j <- entry s+j; lanes past the segment end replicate its LAST entry (consume() zeroes their weight), so a
+    // chunk can always be processed in whole pairs: the padding adds 0 * x of a source row the destination already
+    // uses.  Nothing here touches the loaded value, so the load stays in flight until the next block.
     auto load_chunk = [&](int s, int e, int2& ent) {
         ent = make_int2(0, 0);
-        if (s < e) {
-            const int idx = s + lane;
-            ent = t.entries[min(idx, e - 1)];
-            if (idx >= e) ent.y = 0;
-        }
+        if (s < e) ent = t.entries[min(s + lane, e - 1)];
     };
     // n (<= 64) entries of one chunk; meta = dst_slot<<8 | src_local
     auto consume = [&](const int2& ent, int n, const char* lbuf) {
         const int pk = ((ent.x & 0xFF) << 18) | ((ent.x >> 8) << 2);       // (src_local*1024)<<8 | 4*slot
+        const int wv = lane < n ? ent.y : 0;                               // padding lanes: weight 0
         const int lbase = (int)(size_t)lbuf;                               // LDS byte address of this lane's slice
         auto scal = [&](int j, Sc2& c, Ad2& ad) {
             c.r0 = __builtin_amdgcn_readlane(pk, j); c.r1 = __builtin_amdgcn_readlane(pk, j + 1);
-            c.w0 = (unsigned)__builtin_amdgcn_readlane(ent.y, j); c.w1 = (unsigned)__builtin_amdgcn_readlane(ent.y, j + 1);
+            c.w0 = (unsigned)__builtin_amdgcn_readlane(wv, j); c.w1 = (unsigned)__builtin_amdgcn_readlane(wv, j + 1);
             ad.a0 = lbase + (int)((unsigned)c.r0 >> 8); ad.a1 = lbase + (int)((unsigned)c.r1 >> 8);
         };
         const int ng = (n + 1) >> 1;                      // padded to whole pairs: see load_chunk
