@@ -75,9 +75,15 @@ def main():
 
     rank = int(os.environ.get("RANK", 0)); local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    backend = os.environ.get("WGNN_BENCH_BACKEND", "nccl")       # "gloo" + WGNN_BENCH_SHARE_GPU=1: debug runs of the N>1
+    if os.environ.get("WGNN_BENCH_SHARE_GPU") == "1":            # path on a 1-GPU box (all ranks on cuda:0)
+        local_rank = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -138,7 +144,7 @@ def main():
         d = dict(zip(tag[::2], tag[1::2]))
         ms = sum(ts) / len(ts)
         b = pass_bytes(d["nnz"], d["rows"], d["cols"], d["D"], G)
-        passes.append({"rows": d["rows"], "src_rows": d["cols"], "nnz": d["nnz"], "D": d["D"],
+        passes.append({"kernel": d["kernel"], "rows": d["rows"], "src_rows": d["cols"], "nnz": d["nnz"], "D": d["D"],
                        "launches_per_step": len(ts) // args.steps, "avg_ms": round(ms, 4),
                        "alg_bytes": b, "achieved_GBs": round(b / ms / 1e6, 1)})
     passes.sort(key=lambda p: -p["avg_ms"] * p["launches_per_step"])
@@ -150,7 +156,7 @@ def main():
             traffic = json.loads(tf.read_text()).get(f"{args.config}:{dom['rows']}x{dom['src_rows']}")
         except Exception:
             traffic = None
-    roofline = {"bound": "hbm", "kernel": f"agg_main (rows={dom['rows']}, src={dom['src_rows']}, D={dom['D']})",
+    roofline = {"bound": "hbm", "kernel": f"{dom['kernel']} (rows={dom['rows']}, src={dom['src_rows']}, D={dom['D']})",
                 "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "alg_bytes_per_launch": dom["alg_bytes"], "avg_launch_ms": dom["avg_ms"], "passes": passes,

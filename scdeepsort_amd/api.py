@@ -41,17 +41,20 @@ def _read_expression(path, file_type: str) -> pd.DataFrame:
     return df.transpose(copy=True)
 
 
-def _features(expr: sp.csr_matrix, n_support: int, dense_dim: int, seed) -> np.ndarray:
-    """gene_feat = PCA(dense_dim) of the support cells' (genes x cells) matrix; cell_feat = rownorm(X) . gene_feat
-    (preprocess_internal.py:183-202, preprocess.py:194-210)."""
+def _features(expr: sp.csr_matrix, n_support: int, dense_dim: int, seed, device) -> torch.Tensor:
+    """gene_feat = PCA(dense_dim) of the support cells' (genes x cells) matrix (host, sklearn, like the reference);
+    cell_feat = rownorm(X) . gene_feat on the device through K1 (preprocess_internal.py:183-202, preprocess.py:194-210)."""
     from sklearn.decomposition import PCA
-    dense = expr.toarray().astype(np.float64)
-    k = min(dense_dim, dense.shape[1], n_support)
-    gene_feat = PCA(k, random_state=seed).fit_transform(dense[:n_support].T)
+    dense_sup = expr[:n_support].toarray().astype(np.float64)
+    k = min(dense_dim, dense_sup.shape[1], n_support)
+    gene_feat = PCA(k, random_state=seed).fit_transform(dense_sup.T)
     if k < dense_dim:
         gene_feat = np.pad(gene_feat, ((0, 0), (0, dense_dim - k)))
-    norm = dense / (dense.sum(axis=1, keepdims=True) + 1e-6)
-    return np.concatenate([gene_feat, norm @ gene_feat]).astype(np.float32)
+    gf = torch.from_numpy(gene_feat.astype(np.float32)).to(device)
+    cf = CellGeneGraph.cell_features(torch.from_numpy(expr.indptr.astype(np.int64)).to(device),
+                                     torch.from_numpy(expr.indices.astype(np.int32)).to(device),
+                                     torch.from_numpy(expr.data.astype(np.float32)).to(device), gf)
+    return torch.cat([gf, cf])
 
 
 def _classify(logits: torch.Tensor, unsure_rate: float) -> Tuple[np.ndarray, np.ndarray]:
@@ -107,7 +110,7 @@ class DeepSortClassifier:
             labels += [label2id[t] for t in ty[keep]]
         expr = sp.vstack(mats).tocsr(); expr.sort_indices()
         C, G = expr.shape
-        feats = torch.from_numpy(_features(expr, C, self.dense_dim, self.random_seed)).to(dev)
+        feats = _features(expr, C, self.dense_dim, self.random_seed, dev)
         graph = CellGeneGraph.from_expression(expr, device=dev)
         y = torch.tensor(labels, dtype=torch.long, device=dev)
         perm = np.random.permutation(C)
@@ -192,7 +195,7 @@ def _predict(species, tissue, input_file, model_path: Path, save_path, unsure_ra
     expr = sp.vstack([support, test]).tocsr(); expr.sort_indices()
     n_sup = support.shape[0]
     mask = np.zeros(expr.shape[0], bool); mask[:n_sup] = True           # test cells: gene->cell edges only (preprocess.py:184-187)
-    feats = torch.from_numpy(_features(expr, n_sup, dense_dim, seed)).to(dev)
+    feats = _features(expr, n_sup, dense_dim, seed, dev)
     graph = CellGeneGraph.from_expression(expr, support_mask=mask, device=dev)
     model = GNN(dense_dim, hidden_dim, len(id2label), n_layers, G, activation=F.relu, dropout=0.1).to(dev)
     model.load_state_dict(state)

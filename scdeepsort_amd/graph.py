@@ -225,6 +225,32 @@ class CellGeneGraph:
         gc = AggCsr(t_rowptr, t_col, t_val, t_inv, num_genes, C_, build_plan(thost, chunk, device=dev), thost)
         return CellGeneGraph(num_genes, C_, cg, gc, 0, C_)
 
+    @staticmethod
+    def cell_features(rowptr: torch.Tensor, col: torch.Tensor, raw: torch.Tensor, gene_feat: torch.Tensor,
+                      chunk: int = DEFAULT_CHUNK) -> torch.Tensor:
+        """``cell_feat = rownorm(X) . gene_feat`` with ``rownorm(X)[c,g] = x/(sum_g x + 1e-6)``
+        (preprocess_internal.py:197-199, preprocess.py:205-207) as the same weighted SpMM the hot path uses (K1,
+        NO_ALPHA, no mean, no self-loop) instead of the reference's dense (cells x genes) matrix product."""
+        from .ops import agg_fwd
+        from ._lib import NO_ALPHA
+        dev = col.device
+        C_ = rowptr.shape[0] - 1
+        rowptr32 = rowptr.to(torch.int32).contiguous()
+        nnz = (rowptr32[1:] - rowptr32[:-1]).long()
+        rows = torch.repeat_interleave(torch.arange(C_, device=dev), nnz)
+        rs = torch.zeros(C_, dtype=torch.float64, device=dev).index_add_(0, rows, raw.double())
+        val = (raw.double() / (rs[rows] + 1e-6)).float().contiguous()
+        host = rowptr32.cpu().numpy()
+        csr = AggCsr(rowptr32, col.to(torch.int32).contiguous(), val, torch.ones(C_, device=dev), C_, gene_feat.shape[0],
+                     build_plan(host, chunk, device=dev), host)
+        gf = gene_feat.float().contiguous()
+        D = gf.shape[1]
+        pad = (-D) % 4
+        if pad:
+            gf = torch.nn.functional.pad(gf, (0, pad))
+        out = agg_fwd(csr, None, NO_ALPHA, 0, gf, None, no_mean=True)
+        return out[:, :D] if pad else out
+
     def bytes_resident(self) -> int:
         tot = 0
         for d in (self.cg, self.gc):

@@ -109,7 +109,8 @@ def agg_fwd(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, self_idx: int
     _lib.check(rc, "wgnn_agg_fwd")
     if ev is not None:
         ev[1].record(torch.cuda.current_stream(dev))
-        PROFILE.append((("rows", csr.n_rows, "cols", csr.n_cols, "nnz", csr.nnz, "D", D, "mode", mode), ev[0], ev[1]))
+        PROFILE.append((("rows", csr.n_rows, "cols", csr.n_cols, "nnz", csr.nnz, "D", D, "mode", mode,
+                         "kernel", "agg_main"), ev[0], ev[1]))
     return out
 
 
@@ -204,7 +205,8 @@ def agg_fwd_tiled(csr: AggCsr, tplan, alpha: Optional[torch.Tensor], mode: int, 
     _lib.check(rc, "wgnn_agg_fwd_tiled")
     if ev is not None:
         ev[1].record(torch.cuda.current_stream(dev))
-        PROFILE.append((("rows", csr.n_rows, "cols", csr.n_cols, "nnz", csr.nnz, "D", D, "mode", mode), ev[0], ev[1]))
+        PROFILE.append((("rows", csr.n_rows, "cols", csr.n_cols, "nnz", csr.nnz, "D", D, "mode", mode,
+                         "kernel", "agg_tiled_flat" if D == 256 else "agg_tiled"), ev[0], ev[1]))
     return out
 
 

@@ -326,3 +326,16 @@ def test_simulated_two_shards_match_unsharded():
     e1 = ShardedWgnn.build(m, rp, col, val, G)
     with torch.no_grad():
         assert torch.equal(e1.forward(feats[:G], feats[G:]), want)
+
+
+def test_cell_features_through_k1():
+    """cell_feat = rownorm(X) . gene_feat (preprocess_internal.py:197-199) as a NO_ALPHA aggregation."""
+    c = small_case(cells=150, genes=90, dim=8, seed=4, density=0.3)
+    expr = c["expr"]
+    gf = np.random.default_rng(2).standard_normal((90, 50)).astype(np.float32)        # width 50: not a multiple of 4
+    dense = expr.toarray().astype(np.float64)
+    want = (dense / (dense.sum(1, keepdims=True) + 1e-6)) @ gf.astype(np.float64)
+    got = sda.CellGeneGraph.cell_features(dev(expr.indptr, torch.int64), dev(expr.indices, torch.int32), dev(expr.data), dev(gf))
+    assert got.shape == (150, 50)
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=1e-5)
+    assert np.all(got.cpu().numpy()[3] == 0)                                           # the empty cell
