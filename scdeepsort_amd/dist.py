@@ -69,6 +69,28 @@ def normalise_gene_side(local_deg: torch.Tensor, local_sum: torch.Tensor, local_
     return rescale_gene_side(local_deg, local_sum, g_deg, g_sum, local_val_locally_normalised, row_of_nnz)
 
 
+class _AllReduceSum(torch.autograd.Function):
+    """y = sum over ranks of x.  Every rank's loss depends on the summed value, so the gradient w.r.t. one rank's
+    contribution is the SUM over ranks of the upstream gradients: backward is an all-reduce too."""
+
+    @staticmethod
+    def forward(ctx, x):
+        y = x.clone()
+        all_reduce_sum_(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        all_reduce_sum_(g)
+        return g
+
+
+def all_reduce_sum(x: torch.Tensor) -> torch.Tensor:
+    """Differentiable SUM all-reduce (out of place)."""
+    return _AllReduceSum.apply(x) if world()[1] > 1 else x
+
+
 @dataclass
 class LocalOps:
     """Local arithmetic of one shard (bound to the HIP operators in production)."""
@@ -89,7 +111,10 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
         new_c = ops.cells_layer(p_g, p_c, b, True)
         if not last:
             part = ops.genes_partial(p_c)
-            all_reduce_sum_(part)                       # the ONE data-path collective (X2)
+            if torch.is_grad_enabled() and part.requires_grad:
+                part = all_reduce_sum(part)             # differentiable: backward all-reduces dH1_g
+            else:
+                all_reduce_sum_(part)                   # the ONE data-path collective (X2)
             h_g = ops.genes_finish(part, p_g, b, True)
         h_c = new_c
     Wo, bo = weights[n_layers]
@@ -121,3 +146,23 @@ def all_reduce_grads(params) -> None:
         n = g.numel()
         g.copy_(flat[off:off + n].view_as(g))
         off += n
+
+
+def sharded_train_step(params, weights_fn, feats_g, feats_c_local, labels_local, ops: LocalOps, n_layers: int,
+                       optimizer, seeds_local: Optional[torch.Tensor] = None) -> float:
+    """One full-batch data-parallel training step over cell shards (BASELINE cfg4).
+
+    loss = CrossEntropyLoss(reduction='sum') over this rank's cells (train.py:36); because the loss is a SUM, adding
+    the per-rank parameter gradients (all_reduce_grads) reproduces the single-process gradient exactly, and every rank
+    then applies the identical optimizer step.  Returns the global loss."""
+    logits = sharded_forward(weights_fn(), None, feats_g, feats_c_local, ops, n_layers, gather_logits=False)
+    if seeds_local is not None:
+        logits = logits[seeds_local]
+    loss = torch.nn.functional.cross_entropy(logits, labels_local, reduction="sum")
+    optimizer.zero_grad()
+    loss.backward()
+    all_reduce_grads(params)
+    optimizer.step()
+    total = loss.detach().clone()
+    all_reduce_sum_(total)
+    return float(total)

@@ -290,3 +290,37 @@ def weighted_mean_aggregate(csr: AggCsr, alpha: torch.Tensor, mode: int, self_id
                             h_self: Optional[torch.Tensor], bias: Optional[torch.Tensor] = None, relu: bool = False,
                             row_ids: Optional[torch.Tensor] = None, self_compact: bool = False) -> torch.Tensor:
     return WeightedMeanAggregate.apply(h_src, h_self, alpha, bias, csr, mode, self_idx, relu, row_ids, self_compact)
+
+
+class _WeightedSum(torch.autograd.Function):
+    """out = A @ h_src (plain weighted sum: NO_ALPHA, no mean, no self-loop) - the per-shard partial of the
+    genes<-cells pass.  backward: dh_src = A^T g (K2 over the transposed structure, unit column scale)."""
+
+    @staticmethod
+    def forward(ctx, h_src, csr: AggCsr):
+        ctx.csr = csr
+        return agg_fwd(csr, None, NO_ALPHA, 0, h_src, None, no_mean=True)
+
+    @staticmethod
+    def backward(ctx, g):
+        csr: AggCsr = ctx.csr
+        t = csr.transposed()
+        ones = getattr(csr, "_ones", None)
+        if ones is None or ones.shape[0] != csr.n_rows:
+            ones = torch.ones(csr.n_rows, dtype=torch.float32, device=g.device)
+            csr._ones = ones
+        g = _rowmajor(g.float())
+        D = g.shape[1]
+        dh = torch.empty((t.n_rows, D), dtype=torch.float32, device=g.device)
+        part = _partials(t.plan, D, g.device)
+        rc = _lib.lib().wgnn_agg_bwd_src(
+            _ptr(t.rowptr), _ptr(t.col), _ptr(t.val), None, NO_ALPHA, _ptr(ones), _ptr(g), g.stride(0), None, 0,
+            _ptr(dh), dh.stride(0), None, 0, t.n_rows, D,
+            _ptr(t.plan.items), t.plan.n_items, _ptr(t.plan.long_rows) if t.plan.n_long else None, t.plan.n_long,
+            _ptr(part), t.plan.n_partials, _stream(g.device))
+        _lib.check(rc, "wgnn_agg_bwd_src")
+        return dh, None
+
+
+def weighted_sum(csr: AggCsr, h_src: torch.Tensor) -> torch.Tensor:
+    return _WeightedSum.apply(h_src, csr)

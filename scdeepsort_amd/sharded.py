@@ -13,7 +13,7 @@ from . import dist as D
 from ._lib import NO_ALPHA, SRC_IS_GENE
 from .gnn import GNN
 from .graph import AggCsr, CellGeneGraph, _normalize_on_device, build_plan, DEFAULT_CHUNK
-from .ops import agg_fwd
+from .ops import agg_fwd, weighted_mean_aggregate, weighted_sum
 
 
 class ShardedWgnn:
@@ -56,30 +56,41 @@ class ShardedWgnn:
             world = max(world, 2)
         return ShardedWgnn(model, g, world)
 
-    # -- local arithmetic bound to the HIP kernels -------------------------------------------------
+    # -- local arithmetic bound to the HIP kernels (differentiable: K1 forward, K2/K3 backward) ---------
     def _ops(self) -> D.LocalOps:
         m, g = self.model, self.graph
         G = g.num_genes
-        a = m.alpha.reshape(-1)
 
         def cells_layer(p_g, p_c, b, relu):
-            return agg_fwd(g.cg, a, SRC_IS_GENE, G + 1, p_g, p_c, bias=b, relu=relu)
+            return weighted_mean_aggregate(g.cg, m.alpha, SRC_IS_GENE, G + 1, p_g, p_c, bias=b, relu=relu)
 
         def genes_partial(p_c):
+            if torch.is_grad_enabled() and p_c.requires_grad:
+                return weighted_sum(g.gc, p_c)
             return agg_fwd(g.gc, None, NO_ALPHA, 0, p_c, None, no_mean=True)
 
         def genes_finish(part, p_g, b, relu):
+            a = m.alpha.reshape(-1)
             z = (a[:G].unsqueeze(1) * part + a[G] * p_g) * g.gc.inv_deg.unsqueeze(1) + b
             return F.relu(z) if relu else z
 
         return D.LocalOps(cells_layer, genes_partial, genes_finish)
 
+    def _weights(self):
+        m = self.model
+        return [(l.fc_neigh.weight, l.fc_neigh.bias) for l in m.layers] + [(m.linear.weight, m.linear.bias)]
+
+    def train_step(self, feats_g, feats_c_local, labels_local, optimizer, seeds_local=None) -> float:
+        """Data-parallel full-batch step (cfg4): local CE-sum loss, SUM all-reduce of gradients, identical Adam step."""
+        self.model.train()
+        return D.sharded_train_step(list(self.model.parameters()), self._weights, feats_g, feats_c_local, labels_local,
+                                    self._ops(), self.model.n_layers, optimizer, seeds_local)
+
     def forward(self, feats_g: torch.Tensor, feats_c_local: torch.Tensor, gather_logits: bool = True) -> torch.Tensor:
         m = self.model
         if self.world == 1:
             return m.linear(m.embed(self.graph, (feats_g, feats_c_local)))
-        weights = [(l.fc_neigh.weight, l.fc_neigh.bias) for l in m.layers] + [(m.linear.weight, m.linear.bias)]
-        return D.sharded_forward(weights, None, feats_g, feats_c_local, self._ops(), m.n_layers, gather_logits)
+        return D.sharded_forward(self._weights(), None, feats_g, feats_c_local, self._ops(), m.n_layers, gather_logits)
 
     def forward_alg_bytes(self, dense_dim: int, s: int = 4) -> int:
         """Algorithmic HBM bytes of one 2-layer forward on this rank (SURVEY.md section 8d formula)."""

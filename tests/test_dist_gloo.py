@@ -71,6 +71,24 @@ def _worker(rank, world, port, out_dir):
         full = O.csr_forward(sd, ref, c["feats"].astype(np.float64), 2, dtype=np.float64)
         np.testing.assert_allclose(logits.numpy(), full, atol=1e-6)          # every rank holds ALL cells' logits, in order
 
+        # ---- data-parallel training step (cfg4): grads after SUM all-reduce == single-process autograd grads
+        labels = torch.from_numpy(np.random.default_rng(5).integers(0, 3, C))
+        params = {k: torch.nn.Parameter(v.clone()) for k, v in sd.items()}
+        al = params["alpha"].reshape(-1)
+        tops = D.LocalOps(
+            cells_layer=lambda p_g, p_c, b, relu: torch.relu(((Acg @ (al[:G, None] * p_g)) + al[G + 1] * p_c) * inv_c[:, None] + b),
+            genes_partial=lambda p_c: Agc @ p_c,
+            genes_finish=lambda part, p_g, b, relu: torch.relu((al[:G, None] * part + al[G] * p_g) * inv_g[:, None].double() + b))
+        wfn = lambda: [(params[f"layers.{i}.fc_neigh.weight"], params[f"layers.{i}.fc_neigh.bias"]) for i in range(2)] + \
+                      [(params["linear.weight"], params["linear.bias"])]
+        opt = torch.optim.SGD(list(params.values()), lr=0.0)           # lr 0: inspect the all-reduced grads
+        total = D.sharded_train_step(list(params.values()), wfn, feats[:G], feats[G + lo:G + hi], labels[lo:hi], tops, 2, opt)
+        rg = O.build_reference_graph(c["expr"])
+        loss_ref, grads_ref, _ = O.loss_and_grads(sd, rg, feats, np.arange(G, G + C), labels, 2)
+        assert abs(total - float(loss_ref)) < 1e-5 * max(1.0, abs(float(loss_ref)))
+        for k, p_ in params.items():
+            np.testing.assert_allclose(p_.grad.numpy(), grads_ref[k].numpy(), atol=1e-6, rtol=1e-4, err_msg=k)   # fp32-normalised graph weights in the oracle
+
         # SUM all-reduce of gradients == single-process gradient of the summed loss (train.py:36)
         p = torch.nn.Parameter(torch.ones(5, dtype=torch.float64))
         x = torch.arange(10, dtype=torch.float64).reshape(2, 5)
