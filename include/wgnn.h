@@ -123,6 +123,7 @@ int wgnn_agg_fwd(const int32_t* rowptr, const int32_t* col, const float* val,
  *   entries    : int32[nnz * 2]            {dst_slot_in_wave << 8 | src_row_in_block, weight (f32 bits)}
  *                                          sorted by (tile, block, wave, dst_slot); block = (col-col_begin)/64
  *   seg_ptr    : int32[n_tiles*nblk_max*16 + 1]  entry offsets per (tile, block, wave)
+ *   block_rows : source rows per LDS block the plan was built for (16..255; 2*block_rows*D*4 B <= 160 KiB)
  *   long_rows / partials as in wgnn_agg_fwd (every row of a column-split plan is a "long row").
  *   src_scratch: float[n_src * D], required for WGNN_SRC_IS_GENE: alpha is folded into the source rows
  *                once ((h*alpha), gnn.py:54) instead of once per edge.
@@ -132,7 +133,7 @@ int wgnn_agg_fwd_tiled(const int32_t* rowptr, const float* alpha, int alpha_mode
                        const float* h_self, int64_t ld_self,
                        const int32_t* row_ids, const float* inv_deg, const float* bias,
                        float* out, int64_t ld_out, int64_t n_out, int32_t D, uint32_t flags,
-                       const int32_t* entries, const int32_t* seg_ptr, int32_t nblk_max,
+                       const int32_t* entries, const int32_t* seg_ptr, int32_t nblk_max, int32_t block_rows,
                        const int32_t* tile_items, const int32_t* tile_hdr, int64_t n_tiles,
                        const int32_t* long_rows, int64_t n_long, float* partials, int64_t n_partials,
                        void* stream);

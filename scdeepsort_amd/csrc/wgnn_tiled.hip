@@ -26,10 +26,10 @@ using namespace wgnn;
 
 constexpr int kTW = 16;                       // waves per tile workgroup
 constexpr int kRPW = 16;                      // destination rows per wave
-constexpr int kKB = 64;                       // source rows per LDS block
+constexpr int kKBDefault = 64;                // source rows per LDS block (TArgs::kb; 2*kb*D*4 B of LDS)
 constexpr int kTileRows = kTW * kRPW;         // 256
 // ablation switches (timing experiments only; results are wrong when set)
-constexpr unsigned kDbgNoFill = 1u << 16, kDbgNoCompute = 1u << 17;
+constexpr unsigned kDbgNoFill = 1u << 16, kDbgNoCompute = 1u << 17, kDbgNoBarrier = 1u << 18;
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -41,6 +41,7 @@ struct TArgs {
     const int4* tile_items;   // [n_tiles*256] {row_slot|-1, -, -, partial_slot|-1}
     const int2* tile_hdr;     // [n_tiles] {col_begin, col_end}
     int nblk_max;
+    int kb;                   // source rows per LDS block
 };
 
 // out[r] = scale[r] * in[r]   (alpha folded into the source table; tiny: |table| bytes)
@@ -63,6 +64,7 @@ __global__ void __launch_bounds__(kTW * 64) agg_tiled(const KArgs a, const TArgs
     const int2 hdr = t.tile_hdr[tile];
     const int cb = __builtin_amdgcn_readfirstlane(hdr.x), ce = __builtin_amdgcn_readfirstlane(hdr.y);
     const int row_bytes = a.D * (int)sizeof(float);
+    const int kKB = t.kb;
     const int buf_bytes = kKB * row_bytes;
     const bool active = lane * 16 < row_bytes;
     const int nblk = (ce - cb + kKB - 1) / kKB;
@@ -215,7 +217,8 @@ template <typename TOut, int EPI>
 __global__ void __launch_bounds__(kTW * 64) __attribute__((amdgpu_num_vgpr(48)))
 agg_tiled_flat(const KArgs a, const TArgs t) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int row_bytes = 1024, buf_bytes = kKB * row_bytes;
+    constexpr int row_bytes = 1024;
+    const int kKB = t.kb, buf_bytes = kKB * row_bytes;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int tile = blockIdx.x;
@@ -271,7 +274,7 @@ agg_tiled_flat(const KArgs a, const TArgs t) {
     };
     auto block = [&](int b, int& cs, int& ce0, const int2& cur0, int ns, int ne, int2& nxt0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my DMA pieces of block b and my entry chunk have landed
-        __syncthreads();                                      // everyone's have; everyone is done with block b-1
+        if (!(a.flags & kDbgNoBarrier)) __syncthreads();      // everyone's have; everyone is done with block b-1
         asm volatile("" ::"s"(ns), "s"(ne));                  // retire the scalar loads issued at the end of block b-1
         if (b + 1 < nblk) {
             load_chunk(ns, ne, nxt0);
@@ -322,7 +325,7 @@ agg_tiled_flat(const KArgs a, const TArgs t) {
 
 template <typename TOut, int EPI>
 int launch_tiled(const KArgs& a, const TArgs& t, long n_tiles, hipStream_t st) {
-    const int lds = 2 * kKB * a.D * (int)sizeof(float);
+    const int lds = 2 * t.kb * a.D * (int)sizeof(float);
     static int configured = 0;                       // per instantiation
     if (configured < lds) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_tiled<TOut, EPI>),
@@ -330,13 +333,14 @@ int launch_tiled(const KArgs& a, const TArgs& t, long n_tiles, hipStream_t st) {
             return WGNN_ERR_LAUNCH;
         configured = lds;
     }
+    if (lds > 160 * 1024) return WGNN_ERR_PLAN;
     if (a.D == 256 && !(a.flags & (1u << 19))) {       // bit 19: force the generic (row-visit) kernel, for A/B timing
-        static bool flat_configured = false;
-        if (!flat_configured) {
+        static int flat_configured = 0;
+        if (flat_configured < lds) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_tiled_flat<TOut, EPI>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
                 return WGNN_ERR_LAUNCH;
-            flat_configured = true;
+            flat_configured = lds;
         }
         hipLaunchKernelGGL((agg_tiled_flat<TOut, EPI>), dim3((unsigned)n_tiles), dim3(kTW * 64), lds, st, a, t);
     } else {
@@ -356,7 +360,7 @@ extern "C" int wgnn_agg_fwd_tiled(const int32_t* rowptr, const float* alpha, int
                                   const float* h_self, int64_t ld_self,
                                   const int32_t* row_ids, const float* inv_deg, const float* bias,
                                   float* out, int64_t ld_out, int64_t n_out, int32_t D, uint32_t flags,
-                                  const int32_t* entries, const int32_t* seg_ptr, int32_t nblk_max,
+                                  const int32_t* entries, const int32_t* seg_ptr, int32_t nblk_max, int32_t block_rows,
                                   const int32_t* tile_items, const int32_t* tile_hdr, int64_t n_tiles,
                                   const int32_t* long_rows, int64_t n_long, float* partials, int64_t n_partials,
                                   void* stream) {
@@ -365,7 +369,8 @@ extern "C" int wgnn_agg_fwd_tiled(const int32_t* rowptr, const float* alpha, int
     if (alpha_mode != WGNN_NO_ALPHA && !alpha) return WGNN_ERR_BAD_ARG;
     if (!inv_deg && !rowptr && !(flags & WGNN_FLAG_NO_MEAN)) return WGNN_ERR_BAD_ARG;
     if (D <= 0 || D % 4 || ld_out % 4 || (h_self && ld_self % 4)) return WGNN_ERR_ALIGNMENT;
-    if (D > 256) return WGNN_ERR_UNSUPPORTED;                     // one float4 per lane; 2 x 64 x D x 4 B of LDS
+    if (D > 256) return WGNN_ERR_UNSUPPORTED;                     // one float4 per lane
+    if (block_rows < 16 || block_rows > 255 || 2 * (int64_t)block_rows * D * 4 > 160 * 1024) return WGNN_ERR_PLAN;
     if (!aligned16(h_src) || !aligned16(out) || (h_self && !aligned16(h_self)) || (bias && !aligned16(bias)))
         return WGNN_ERR_ALIGNMENT;
     if (n_tiles > 0 && (!tile_items || !tile_hdr || !entries || !seg_ptr)) return WGNN_ERR_BAD_ARG;
@@ -387,7 +392,7 @@ extern "C" int wgnn_agg_fwd_tiled(const int32_t* rowptr, const float* alpha, int
     a.out = out; a.ld_out = ld_out; a.D = D; a.flags = flags;
     a.long_rows = reinterpret_cast<const int4*>(long_rows); a.n_long = n_long; a.partials = partials;
     TArgs t{reinterpret_cast<const int2*>(entries), seg_ptr, reinterpret_cast<const int4*>(tile_items),
-            reinterpret_cast<const int2*>(tile_hdr), nblk_max};
+            reinterpret_cast<const int2*>(tile_hdr), nblk_max, block_rows};
     int rc = launch_tiled<float, EPI_FWD>(a, t, n_tiles, st);
     if (rc) return rc;
     if (n_long > 0) return launch_finalize_fwd_f32(a, st);

@@ -119,11 +119,15 @@ class AggCsr:
                              build_plan(host, self.plan.chunk, device=dev), host)
         return self._t
 
-    def tile_plan(self):
-        """Lazily built plan for the LDS-streamed kernel (heuristic tile geometry, see build_tile_plan)."""
+    def tile_plan(self, block_rows: int = 64):
+        """Lazily built plan for the LDS-streamed kernel (heuristic tile geometry, see build_tile_plan), cached per
+        LDS block height."""
         if self._tile_plan is None:
-            self._tile_plan = build_tile_plan(self, *auto_tile_geometry(self.n_rows, self.n_cols))
-        return self._tile_plan
+            self._tile_plan = {}
+        if block_rows not in self._tile_plan:
+            self._tile_plan[block_rows] = build_tile_plan(self, *auto_tile_geometry(self.n_rows, self.n_cols),
+                                                          block_rows=block_rows)
+        return self._tile_plan[block_rows]
 
     def subplan(self, row_ids: torch.Tensor) -> Tuple[torch.Tensor, Plan]:
         """Plan restricted to a seed subset (one NodeFlow batch, train.py:71-81).  Not cached: the id
@@ -277,6 +281,7 @@ class TilePlan:
     entries: Optional[torch.Tensor] = None     # int32 [nnz, 2]  {dst_slot<<8 | src_local, weight bits}
     seg_ptr: Optional[torch.Tensor] = None     # int32 [n_tiles*nblk_max*16 + 1]
     nblk_max: int = 0
+    block_rows: int = 64
 
     @property
     def n_tiles(self) -> int:
@@ -301,7 +306,7 @@ def auto_tile_geometry(n_rows: int, n_cols: int, n_cus: int = 256) -> Tuple[int,
 
 
 def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits: int = 1,
-                    n_cus: int = 256) -> TilePlan:
+                    n_cus: int = 256, block_rows: int = 64) -> TilePlan:
     """Group the rows of ``csr`` into tiles of <= 256 rows (nnz-balanced across tiles and across the 16
     waves of a tile) and optionally split the column (source) range so hub rows spread over several
     workgroups.  Pure index arithmetic on the device; runs once per graph."""
@@ -323,7 +328,7 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
     slot_in_wave = rnd // TILE_WAVES
     local = wave * (TILE_ROWS // TILE_WAVES) + slot_in_wave
     # column splits on 64-row block boundaries
-    blk = 64
+    blk = block_rows
     per_split = -(-(-(-S // blk)) // n_col_splits) * blk
     bounds = torch.arange(n_col_splits + 1, device=dev, dtype=torch.int64) * per_split
     bounds[-1] = S
@@ -382,4 +387,4 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
     entries = torch.stack([meta[perm], csr.val.view(torch.int32)[perm]], 1).contiguous()
     del perm, meta
     return TilePlan(items.reshape(-1, TILE_ROWS, 4).contiguous(), hdr.reshape(-1, 2).contiguous(), long_rows, n_part,
-                    n_row_tiles, n_col_splits, entries, seg_ptr.to(torch.int32), nblk_max)
+                    n_row_tiles, n_col_splits, entries, seg_ptr.to(torch.int32), nblk_max, block_rows)

@@ -70,7 +70,7 @@ def agg_fwd(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, self_idx: int
         raise WgnnError(f"feature width {D} must be a multiple of 4")
     if (TILED_MIN_WORK is not None and row_ids is None and out is None and h_src.dtype == torch.float32
             and (out_dtype in (None, torch.float32)) and D <= 256 and csr.nnz * D >= TILED_MIN_WORK):
-        return agg_fwd_tiled(csr, csr.tile_plan(), alpha, mode, self_idx, h_src, h_self, bias=bias, relu=relu,
+        return agg_fwd_tiled(csr, csr.tile_plan(tiled_block_rows(D)), alpha, mode, self_idx, h_src, h_self, bias=bias, relu=relu,
                              no_mean=no_mean)
     if h_self is not None:
         h_self = _rowmajor(h_self)
@@ -169,6 +169,11 @@ def agg_bwd_alpha(csr: AggCsr, g: torch.Tensor, h_src: torch.Tensor, h_self: Opt
     return d_row, d_self
 
 
+def tiled_block_rows(D: int) -> int:
+    """Source rows per LDS block: 80 x 1 KiB x 2 buffers = all 160 KiB of a CU at D = 256 (measured best), else 64."""
+    return 80 if D == 256 else 64
+
+
 def agg_fwd_tiled(csr: AggCsr, tplan, alpha: Optional[torch.Tensor], mode: int, self_idx: int,
                   h_src: torch.Tensor, h_self: Optional[torch.Tensor], *, bias: Optional[torch.Tensor] = None,
                   relu: bool = False, no_mean: bool = False) -> torch.Tensor:
@@ -200,7 +205,7 @@ def agg_fwd_tiled(csr: AggCsr, tplan, alpha: Optional[torch.Tensor], mode: int, 
         _ptr(csr.rowptr), _ptr(alpha), mode, self_idx,
         _ptr(h_src), h_src.shape[0], _ptr(scratch), _ptr(h_self), h_self.stride(0) if h_self is not None else 0,
         None, _ptr(csr.inv_deg), _ptr(bias), _ptr(out), out.stride(0), csr.n_rows, D, flags,
-        _ptr(tplan.entries), _ptr(tplan.seg_ptr), tplan.nblk_max, _ptr(tplan.items), _ptr(tplan.hdr), tplan.n_tiles,
+        _ptr(tplan.entries), _ptr(tplan.seg_ptr), tplan.nblk_max, tplan.block_rows, _ptr(tplan.items), _ptr(tplan.hdr), tplan.n_tiles,
         _ptr(tplan.long_rows) if n_long else None, n_long, _ptr(part), tplan.n_partials, _stream(dev))
     _lib.check(rc, "wgnn_agg_fwd_tiled")
     if ev is not None:

@@ -14,7 +14,7 @@ def timeit(f,n=5):
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.perf_counter()-t)/n*1e3
 tpc=build_tile_plan(g.cg,512,1); tpg=build_tile_plan(g.gc,80,16)
-for name,fl in [('full',0),('nofill',1<<16),('nocompute',1<<17),('nocompute+nofill',(1<<16)|(1<<17))]:
+for name,fl in [('full',0),('nofill',1<<16),('nocompute',1<<17),('nocompute+nofill',(1<<16)|(1<<17)),('nofill+nobarrier',(1<<16)|(1<<18)),('nobarrier',(1<<18))]:
     ops.DEBUG_FLAGS=fl
     tc=timeit(lambda: ops.agg_fwd_tiled(g.cg,tpc,alpha,sda.SRC_IS_GENE,G+1,hg,hc))
     tg=timeit(lambda: ops.agg_fwd_tiled(g.gc,tpg,alpha,sda.DST_IS_GENE,G,hc,hg))

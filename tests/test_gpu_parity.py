@@ -228,7 +228,8 @@ def test_full_size_properties_cfg2():
 @pytest.mark.parametrize("D", [64, 128, 256])
 @pytest.mark.parametrize("geom", [(None, 1), (3, 1), (2, 4), (5, 7)])
 @pytest.mark.parametrize("direction", ["cells", "genes"])
-def test_tiled_kernel_matches_oracle(D, geom, direction):
+@pytest.mark.parametrize("kb", [64, 80])
+def test_tiled_kernel_matches_oracle(D, geom, direction, kb):
     from scdeepsort_amd.graph import build_tile_plan
     from scdeepsort_amd import ops
     c = small_case(cells=700, genes=333, dim=D, seed=D + 7, density=0.25, test_cells=50)
@@ -239,11 +240,11 @@ def test_tiled_kernel_matches_oracle(D, geom, direction):
     Hg, Hc = c["feats"][:G], c["feats"][G:]
     zc, zg = O.csr_aggregate(cg, alpha, Hg.astype(np.float64), Hc.astype(np.float64))
     if direction == "cells":
-        tp = build_tile_plan(g.cg, *geom)
+        tp = build_tile_plan(g.cg, *geom, block_rows=kb)
         out = ops.agg_fwd_tiled(g.cg, tp, dev(alpha), sda.SRC_IS_GENE, G + 1, dev(Hg), dev(Hc), bias=dev(bias), relu=True)
         want = np.maximum(zc + bias, 0)
     else:
-        tp = build_tile_plan(g.gc, *geom)
+        tp = build_tile_plan(g.gc, *geom, block_rows=kb)
         out = ops.agg_fwd_tiled(g.gc, tp, dev(alpha), sda.DST_IS_GENE, G, dev(Hc), dev(Hg), bias=dev(bias), relu=True)
         want = np.maximum(zg + bias, 0)
     assert tp.n_col_splits == geom[1]
