@@ -181,6 +181,28 @@ int wgnn_agg_bwd_alpha(const int32_t* rowptr, const int32_t* col, const float* v
                        void* stream);
 
 /* ---------------------------------------------------------------------------
+ * K2t / K3t  LDS-streamed variants of K2 / K3 (D <= 256, f32, contiguous rows), same tile-plan layout as K1t.
+ *   K2t runs over the tile plan of the TRANSPOSED structure; `col_scale[r]` = inv_deg[r] (x alpha[r] for
+ *   WGNN_DST_IS_GENE) is folded into the gradient rows once (g_scratch: float[n_dst*D]).
+ *   K3t runs over the forward structure's tile plan.
+ * ------------------------------------------------------------------------- */
+int wgnn_agg_bwd_src_tiled(const float* alpha, int alpha_mode, const float* col_scale,
+                           const float* g, int64_t n_dst, float* g_scratch,
+                           const float* h_src, int64_t ld_src, float* dh_src, int64_t ld_dh, float* dalpha,
+                           int accumulate, int64_t n_src, int32_t D,
+                           const int32_t* entries, const int32_t* seg_ptr, int32_t nblk_max, int32_t block_rows,
+                           const int32_t* tile_items, const int32_t* tile_hdr, int64_t n_tiles,
+                           const int32_t* long_rows, int64_t n_long, float* partials, int64_t n_partials,
+                           void* stream);
+int wgnn_agg_bwd_alpha_tiled(const float* inv_deg, const float* g, int64_t ld_g,
+                             const float* h_src, const float* h_self, int64_t ld_self,
+                             float* dalpha_row, float* dself_row, int64_t n_out, int32_t D,
+                             const int32_t* entries, const int32_t* seg_ptr, int32_t nblk_max, int32_t block_rows,
+                             const int32_t* tile_items, const int32_t* tile_hdr, int64_t n_tiles,
+                             const int32_t* long_rows, int64_t n_long, float* partials, int64_t n_partials,
+                             void* stream);
+
+/* ---------------------------------------------------------------------------
  * K4  graph-operand normalisation: normalize_weight (preprocess_internal.py:15-23)
  *     val_out[j] = deg_r * val_in[j] / sum_{j in row r} val_in[j]      for rows with >= 1 entry
  *     inv_deg[r] = 1 / (deg_r + 1)                                     (if inv_deg != NULL)

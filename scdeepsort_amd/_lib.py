@@ -28,6 +28,10 @@ SIGNATURES = {
     "wgnn_agg_fwd_tiled": (C.c_int, [_vp, _vp, _int, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp,
                                      _vp, _i64, _i64, _i32, _u32, _vp, _vp, _i32, _i32, _vp, _vp, _i64,
                                      _vp, _i64, _vp, _i64, _vp]),
+    "wgnn_agg_bwd_src_tiled": (C.c_int, [_vp, _int, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _int, _i64, _i32,
+                                         _vp, _vp, _i32, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "wgnn_agg_bwd_alpha_tiled": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i32,
+                                           _vp, _vp, _i32, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "wgnn_agg_bwd_src": (C.c_int, [_vp, _vp, _vp, _vp, _int, _vp, _vp, _i64, _vp, _i64,
                                    _vp, _i64, _vp, _int, _i64, _i32,
                                    _vp, _i64, _vp, _i64, _vp, _i64, _vp]),

@@ -174,10 +174,12 @@ int dispatch_width(const KArgs& a, hipStream_t st) {
 
 namespace wgnn {
 // used by wgnn_tiled.hip: fold the partial sums of column-split tiles (same finalize kernel, same epilogue)
-int launch_finalize_fwd_f32(const KArgs& a, hipStream_t st) {
+int launch_finalize_f32(const KArgs& a, int epi, hipStream_t st) {
     KArgs b = a;
     b.n_items = 0;
-    return dispatch_width<float, float, EPI_FWD>(b, st);
+    if (epi == EPI_FWD) return dispatch_width<float, float, EPI_FWD>(b, st);
+    if (epi == EPI_BWD_SRC) return dispatch_width<float, float, EPI_BWD_SRC>(b, st);
+    return dispatch_width<float, float, EPI_BWD_ALPHA>(b, st);
 }
 }  // namespace wgnn
 

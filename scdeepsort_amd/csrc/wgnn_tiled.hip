@@ -352,7 +352,7 @@ int launch_tiled(const KArgs& a, const TArgs& t, long n_tiles, hipStream_t st) {
 }  // namespace
 
 namespace wgnn {
-int launch_finalize_fwd_f32(const KArgs& a, hipStream_t st);     // defined in wgnn_kernels.hip
+int launch_finalize_f32(const KArgs& a, int epi, hipStream_t st);     // defined in wgnn_kernels.hip
 }
 
 extern "C" int wgnn_agg_fwd_tiled(const int32_t* rowptr, const float* alpha, int alpha_mode, int32_t self_idx,
@@ -395,6 +395,79 @@ extern "C" int wgnn_agg_fwd_tiled(const int32_t* rowptr, const float* alpha, int
             reinterpret_cast<const int2*>(tile_hdr), nblk_max, block_rows};
     int rc = launch_tiled<float, EPI_FWD>(a, t, n_tiles, st);
     if (rc) return rc;
-    if (n_long > 0) return launch_finalize_fwd_f32(a, st);
+    if (n_long > 0) return launch_finalize_f32(a, EPI_FWD, st);
+    return WGNN_OK;
+}
+
+// ---- tiled backward: K2 over the transposed structure, K3 on the forward structure -------------------------
+static int tiled_common_check(int32_t D, int32_t block_rows, const void* entries, const void* seg_ptr, const void* tile_items,
+                              const void* tile_hdr, int64_t n_tiles, const void* long_rows, int64_t n_long,
+                              const float* partials, int64_t n_partials) {
+    if (D <= 0 || D % 4) return WGNN_ERR_ALIGNMENT;
+    if (D > 256) return WGNN_ERR_UNSUPPORTED;
+    if (block_rows < 16 || block_rows > 255 || 2 * (int64_t)block_rows * D * 4 > 160 * 1024) return WGNN_ERR_PLAN;
+    if (n_tiles < 0 || (n_tiles > 0 && (!tile_items || !tile_hdr || !entries || !seg_ptr))) return WGNN_ERR_BAD_ARG;
+    if (n_long > 0 && (!long_rows || !partials || n_partials <= 0)) return WGNN_ERR_WORKSPACE;
+    return WGNN_OK;
+}
+
+extern "C" int wgnn_agg_bwd_src_tiled(const float* alpha, int alpha_mode, const float* col_scale,
+                                      const float* g, int64_t n_dst, float* g_scratch,
+                                      const float* h_src, int64_t ld_src, float* dh_src, int64_t ld_dh, float* dalpha,
+                                      int accumulate, int64_t n_src, int32_t D,
+                                      const int32_t* entries, const int32_t* seg_ptr, int32_t nblk_max, int32_t block_rows,
+                                      const int32_t* tile_items, const int32_t* tile_hdr, int64_t n_tiles,
+                                      const int32_t* long_rows, int64_t n_long, float* partials, int64_t n_partials,
+                                      void* stream) {
+    int rc = tiled_common_check(D, block_rows, entries, seg_ptr, tile_items, tile_hdr, n_tiles, long_rows, n_long, partials, n_partials);
+    if (rc) return rc;
+    if (!g || !dh_src || !col_scale || !g_scratch || n_src < 0 || n_dst < 0) return WGNN_ERR_BAD_ARG;
+    if (alpha_mode < WGNN_SRC_IS_GENE || alpha_mode > WGNN_NO_ALPHA) return WGNN_ERR_BAD_ARG;
+    if (alpha_mode != WGNN_NO_ALPHA && !alpha) return WGNN_ERR_BAD_ARG;
+    if (ld_dh % 4 || (h_src && ld_src % 4)) return WGNN_ERR_ALIGNMENT;
+    if (!aligned16(g) || !aligned16(g_scratch) || !aligned16(dh_src) || (h_src && !aligned16(h_src))) return WGNN_ERR_ALIGNMENT;
+    if (n_src == 0 || n_tiles == 0) return WGNN_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // per-destination factors (inv_deg[r], x alpha[r] for cell->gene edges) are folded into the gradient rows once
+    const long n4 = (long)n_dst * (D / 4);
+    hipLaunchKernelGGL(scale_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, g, col_scale, g_scratch, (long)n_dst, D / 4);
+    KArgs a{};
+    a.src = g_scratch; a.ld_src = D; a.alpha = alpha; a.mode = alpha_mode;
+    a.self = h_src; a.ld_self = ld_src; a.out = dh_src; a.ld_out = ld_dh; a.aux1 = dalpha;
+    a.D = D; a.flags = WGNN_FLAG_NO_MEAN; a.accumulate = accumulate;
+    a.long_rows = reinterpret_cast<const int4*>(long_rows); a.n_long = n_long; a.partials = partials;
+    TArgs t{reinterpret_cast<const int2*>(entries), seg_ptr, reinterpret_cast<const int4*>(tile_items),
+            reinterpret_cast<const int2*>(tile_hdr), nblk_max, block_rows};
+    rc = launch_tiled<float, EPI_BWD_SRC>(a, t, n_tiles, st);
+    if (rc) return rc;
+    if (n_long > 0) return launch_finalize_f32(a, EPI_BWD_SRC, st);
+    return WGNN_OK;
+}
+
+extern "C" int wgnn_agg_bwd_alpha_tiled(const float* inv_deg, const float* g, int64_t ld_g,
+                                        const float* h_src, const float* h_self, int64_t ld_self,
+                                        float* dalpha_row, float* dself_row, int64_t n_out, int32_t D,
+                                        const int32_t* entries, const int32_t* seg_ptr, int32_t nblk_max, int32_t block_rows,
+                                        const int32_t* tile_items, const int32_t* tile_hdr, int64_t n_tiles,
+                                        const int32_t* long_rows, int64_t n_long, float* partials, int64_t n_partials,
+                                        void* stream) {
+    int rc = tiled_common_check(D, block_rows, entries, seg_ptr, tile_items, tile_hdr, n_tiles, long_rows, n_long, partials, n_partials);
+    if (rc) return rc;
+    if (!g || !h_src || !inv_deg || n_out < 0) return WGNN_ERR_BAD_ARG;
+    if (ld_g % 4 || (h_self && ld_self % 4)) return WGNN_ERR_ALIGNMENT;
+    if (!aligned16(g) || !aligned16(h_src) || (h_self && !aligned16(h_self))) return WGNN_ERR_ALIGNMENT;
+    if (n_out == 0 || n_tiles == 0) return WGNN_OK;
+    KArgs a{};
+    a.src = h_src; a.ld_src = D; a.mode = WGNN_NO_ALPHA;
+    a.self = h_self; a.ld_self = ld_self; a.inv_deg = inv_deg;
+    a.g = g; a.ld_g = ld_g; a.aux1 = dalpha_row; a.aux2 = dself_row;
+    a.D = D; a.flags = 0;
+    a.long_rows = reinterpret_cast<const int4*>(long_rows); a.n_long = n_long; a.partials = partials;
+    TArgs t{reinterpret_cast<const int2*>(entries), seg_ptr, reinterpret_cast<const int4*>(tile_items),
+            reinterpret_cast<const int2*>(tile_hdr), nblk_max, block_rows};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = launch_tiled<float, EPI_BWD_ALPHA>(a, t, n_tiles, st);
+    if (rc) return rc;
+    if (n_long > 0) return launch_finalize_f32(a, EPI_BWD_ALPHA, st);
     return WGNN_OK;
 }

@@ -132,6 +132,22 @@ def agg_bwd_src(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, g: torch.
         h_src = _rowmajor(h_src.float())
     if alpha is not None:
         alpha = alpha.reshape(-1).float().contiguous()
+    if TILED_MIN_WORK is not None and D <= 256 and csr.nnz * D >= TILED_MIN_WORK:
+        # K2t: LDS-streamed kernel over the transposed structure; per-destination factors folded into g once
+        tp = t.tile_plan(tiled_block_rows(D))
+        scale = csr.inv_deg if mode != DST_IS_GENE else csr.inv_deg * alpha[: csr.n_rows]
+        g = g.contiguous()
+        scratch = torch.empty_like(g)
+        part = torch.empty(tp.n_partials * D, dtype=torch.float32, device=dev) if tp.n_partials else None
+        n_long = tp.long_rows.shape[0]
+        rc = _lib.lib().wgnn_agg_bwd_src_tiled(
+            _ptr(alpha), mode, _ptr(scale.contiguous()), _ptr(g), g.shape[0], _ptr(scratch),
+            _ptr(h_src), h_src.stride(0) if h_src is not None else 0, _ptr(dh_src), dh_src.stride(0), _ptr(dalpha),
+            int(accumulate), t.n_rows, D, _ptr(tp.entries), _ptr(tp.seg_ptr), tp.nblk_max, tp.block_rows,
+            _ptr(tp.items), _ptr(tp.hdr), tp.n_tiles, _ptr(tp.long_rows) if n_long else None, n_long,
+            _ptr(part), tp.n_partials, _stream(dev))
+        _lib.check(rc, "wgnn_agg_bwd_src_tiled")
+        return dh_src
     part = _partials(t.plan, D, dev)
     rc = _lib.lib().wgnn_agg_bwd_src(
         _ptr(t.rowptr), _ptr(t.col), _ptr(t.val), _ptr(alpha), mode, _ptr(csr.inv_deg),
@@ -158,6 +174,18 @@ def agg_bwd_alpha(csr: AggCsr, g: torch.Tensor, h_src: torch.Tensor, h_self: Opt
         h_self = _rowmajor(h_self.float())
     d_row = torch.empty(n_out, dtype=torch.float32, device=dev)
     d_self = torch.empty(n_out, dtype=torch.float32, device=dev) if h_self is not None else None
+    if (TILED_MIN_WORK is not None and row_ids is None and D <= 256 and csr.nnz * D >= TILED_MIN_WORK):
+        tp = csr.tile_plan(tiled_block_rows(D))                                   # K3t
+        h_src = h_src.contiguous()
+        part = torch.empty(tp.n_partials * D, dtype=torch.float32, device=dev) if tp.n_partials else None
+        n_long = tp.long_rows.shape[0]
+        rc = _lib.lib().wgnn_agg_bwd_alpha_tiled(
+            _ptr(csr.inv_deg), _ptr(g), g.stride(0), _ptr(h_src), _ptr(h_self),
+            h_self.stride(0) if h_self is not None else 0, _ptr(d_row), _ptr(d_self), n_out, D,
+            _ptr(tp.entries), _ptr(tp.seg_ptr), tp.nblk_max, tp.block_rows, _ptr(tp.items), _ptr(tp.hdr), tp.n_tiles,
+            _ptr(tp.long_rows) if n_long else None, n_long, _ptr(part), tp.n_partials, _stream(dev))
+        _lib.check(rc, "wgnn_agg_bwd_alpha_tiled")
+        return d_row, d_self
     part = _partials(plan, D, dev)
     rc = _lib.lib().wgnn_agg_bwd_alpha(
         _ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), _ptr(csr.inv_deg), _ptr(ids),
@@ -309,21 +337,15 @@ class _WeightedSum(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         csr: AggCsr = ctx.csr
-        t = csr.transposed()
         ones = getattr(csr, "_ones", None)
         if ones is None or ones.shape[0] != csr.n_rows:
             ones = torch.ones(csr.n_rows, dtype=torch.float32, device=g.device)
             csr._ones = ones
-        g = _rowmajor(g.float())
-        D = g.shape[1]
-        dh = torch.empty((t.n_rows, D), dtype=torch.float32, device=g.device)
-        part = _partials(t.plan, D, g.device)
-        rc = _lib.lib().wgnn_agg_bwd_src(
-            _ptr(t.rowptr), _ptr(t.col), _ptr(t.val), None, NO_ALPHA, _ptr(ones), _ptr(g), g.stride(0), None, 0,
-            _ptr(dh), dh.stride(0), None, 0, t.n_rows, D,
-            _ptr(t.plan.items), t.plan.n_items, _ptr(t.plan.long_rows) if t.plan.n_long else None, t.plan.n_long,
-            _ptr(part), t.plan.n_partials, _stream(g.device))
-        _lib.check(rc, "wgnn_agg_bwd_src")
+        saved, csr.inv_deg = csr.inv_deg, ones                # plain A^T g: unit per-destination factor
+        try:
+            dh = agg_bwd_src(csr, None, NO_ALPHA, g, None)
+        finally:
+            csr.inv_deg = saved
         return dh, None
 
 
