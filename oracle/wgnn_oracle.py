@@ -170,12 +170,14 @@ class _InEdges:
         counts = np.bincount(g.dst, minlength=g.num_nodes)
         self.ptr = np.concatenate([[0], np.cumsum(counts)])
 
-    def of(self, nodes: np.ndarray, rng: Optional[np.random.Generator], num_neighbors: int):
+    def of(self, nodes: np.ndarray, rng: Optional[np.random.Generator], num_neighbors: int, picker=None, block=0):
         srcs, dsts, ws = [], [], []
         for j, v in enumerate(nodes):
             lo, hi = self.ptr[v], self.ptr[v + 1]
             sel = np.arange(lo, hi)
-            if num_neighbors and num_neighbors < hi - lo:       # train.py:37-40: uniform w/o replacement
+            if picker is not None:                              # an externally drawn sample (parity tests)
+                sel = sel[np.isin(self.src[sel], picker(block, int(v)))]
+            elif num_neighbors and num_neighbors < hi - lo:     # train.py:37-40: uniform w/o replacement
                 sel = np.sort(rng.choice(sel, size=num_neighbors, replace=False))
             srcs.append(self.src[sel]); ws.append(self.w[sel]); dsts.append(np.full(len(sel), j, dtype=np.int64))
         return np.concatenate(srcs), np.concatenate(dsts), np.concatenate(ws)
@@ -183,7 +185,7 @@ class _InEdges:
 
 def nodeflow_forward(sd: Dict[str, torch.Tensor], g: RefGraph, features: torch.Tensor, seeds: Sequence[int],
                      n_layers: int, num_neighbors: int = 0, rng: Optional[np.random.Generator] = None,
-                     dropout_masks: Optional[List[torch.Tensor]] = None) -> torch.Tensor:
+                     dropout_masks: Optional[List[torch.Tensor]] = None, picker=None) -> torch.Tensor:
     """GNN.forward on the NodeFlow of one seed batch (gnn.py:58-68 + train.py:71-81).
 
     NodeFlow emulation [DGL-ext semantics]: layer L = seeds; layer i = unique
@@ -191,13 +193,15 @@ def nodeflow_forward(sd: Dict[str, torch.Tensor], g: RefGraph, features: torch.T
     With ``num_neighbors == 0`` every in-edge is taken (expand_factor >= max degree,
     train.py:37-38).  ``dropout_masks[i]`` (already scaled by 1/(1-p), indexed by
     *parent* node id) reproduces ``self.dropout(h)`` on layer i's rows (gnn.py:62-63).
+    ``picker(block, v)`` (optional) returns the parent ids of the in-edge sources drawn for node ``v`` in block
+    ``block`` (v itself = its self-loop): lets a test replay a sample drawn elsewhere instead of ``rng``.
     Returns logits for ``seeds`` in the given order.
     """
     ine = _InEdges(g)
     layers = [np.asarray(seeds, dtype=np.int64)]
     blocks = []
-    for _ in range(n_layers):
-        e_src_parent, e_dst_local, e_w = ine.of(layers[0], rng, num_neighbors)
+    for t in range(n_layers):
+        e_src_parent, e_dst_local, e_w = ine.of(layers[0], rng, num_neighbors, picker, n_layers - 1 - t)
         prev, e_src_local = np.unique(e_src_parent, return_inverse=True)
         blocks.insert(0, (e_src_local, e_dst_local, torch.from_numpy(e_w).to(features.dtype)))
         layers.insert(0, prev)

@@ -69,8 +69,7 @@ class DeepSortClassifier:
     def __init__(self, species, tissue, dense_dim=400, hidden_dim=200, batch_size=256, dropout=0.1, gpu_id=-1,
                  file_type='csv', learning_rate=0.001, weight_decay=5e-4, n_epochs=300, n_layers=1, threshold=0,
                  num_neighbors=None, exclude_rate=0.005, random_seed=None, validation_fraction=0.1):
-        if num_neighbors not in (None, 0):
-            raise NotImplementedError("neighbour subsampling (train.py:37-40) is not built yet: all neighbours are used")
+        self.num_neighbors = int(num_neighbors or 0)          # 0 / None = every in-edge (train.py:37-38)
         self.species, self.tissue = species, tissue
         self.dense_dim, self.hidden_dim, self.batch_size, self.dropout = dense_dim, hidden_dim, batch_size, dropout
         self.gpu_id, self.file_type = gpu_id, file_type
@@ -120,6 +119,10 @@ class DeepSortClassifier:
                     dropout=self.dropout).to(dev)
         opt = torch.optim.Adam(model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay)   # train.py:34-35
         best, self.history = -1.0, []
+        sample_gen = None
+        if self.num_neighbors:                                               # train.py:39-40,71-78
+            sample_gen = torch.Generator(device=dev)
+            sample_gen.manual_seed(self.random_seed if self.random_seed is not None else torch.initial_seed() % 2 ** 31)
         save_path = Path(save_path) if save_path is not None else None
         if save_path is not None:
             save_path.mkdir(parents=True, exist_ok=True)
@@ -141,7 +144,7 @@ class DeepSortClassifier:
             total = 0.0
             order = train_ids[torch.randperm(len(train_ids), device=dev)]
             for batch in torch.split(order, self.batch_size):                # train.py:71-87
-                logits = model(graph, feats, seeds=batch)
+                logits = model(graph, feats, seeds=batch, num_neighbors=self.num_neighbors, generator=sample_gen)
                 loss = F.cross_entropy(logits, y[batch - G], reduction='sum')     # train.py:36
                 opt.zero_grad(); loss.backward(); opt.step()
                 total += float(loss.detach())

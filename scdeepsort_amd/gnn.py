@@ -30,7 +30,7 @@ import torch.nn.functional as F
 
 from ._lib import DST_IS_GENE, SRC_IS_GENE
 from .graph import CellGeneGraph
-from .ops import weighted_mean_aggregate
+from .ops import weighted_mean_aggregate, weighted_sum
 
 
 class NodeUpdate(nn.Module):
@@ -127,11 +127,61 @@ class GNN(nn.Module):
             h_g, h_c = self._layer(g, layer, h_g, h_c, want_genes=not last, cell_rows=cell_rows if last else None)
         return h_c
 
+    def embed_sampled(self, g: CellGeneGraph, features, nodeflow) -> torch.Tensor:
+        """Seed-cell embeddings over a drawn NodeFlow (``sampler.sample_nodeflow``): the ``num_neighbors > 0`` mode
+        of train.py:37-40.  Aggregate-first (the reference's literal order) on the compact destination rows; the
+        mean divides by the number of DRAWN edges, the self-loop counts only where it was drawn."""
+        G = self.gene_num
+        if isinstance(features, (tuple, list)):
+            h_g, h_c = features
+        else:
+            h_g, h_c = features[:G], features[G:]
+        a = self.alpha.reshape(-1)
+        n_blocks = len(nodeflow.blocks)
+        for i, (layer, (cb, gb)) in enumerate(zip(self.layers, nodeflow.blocks)):
+            if self.dropout is not None:
+                h_g, h_c = self.dropout(h_g), self.dropout(h_c)
+
+            def update(z):
+                x = layer.fc_neigh(z)
+                if layer.activation is not None:
+                    x = layer.activation(x)
+                if layer.norm is not None:
+                    x = layer.norm(x)
+                return x
+
+            z_c = weighted_mean_aggregate(cb.csr, self.alpha, SRC_IS_GENE, G + 1, h_g, None)
+            z_c = z_c + (a[G + 1] * cb.self_drawn * cb.csr.inv_deg).unsqueeze(1) * h_c[cb.rows]
+            out_c = update(z_c)
+            if i == n_blocks - 1:
+                return out_c
+            nh_c = torch.zeros((h_c.shape[0], out_c.shape[1]), dtype=out_c.dtype, device=out_c.device)
+            nh_c = nh_c.index_copy(0, cb.rows, out_c)
+            nh_g = torch.zeros((G, out_c.shape[1]), dtype=out_c.dtype, device=out_c.device)
+            if gb is not None:
+                s_g = weighted_sum(gb.csr, h_c)
+                z_g = (a[gb.rows].unsqueeze(1) * s_g + (a[G] * gb.self_drawn).unsqueeze(1) * h_g[gb.rows]) \
+                    * gb.csr.inv_deg.unsqueeze(1)
+                nh_g = nh_g.index_copy(0, gb.rows, update(z_g))
+            h_g, h_c = nh_g, nh_c
+        raise AssertionError("unreachable")
+
     def forward(self, g: CellGeneGraph, features: Optional[torch.Tensor] = None,
-                seeds: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """Logits ``[len(seeds), n_classes]`` (all cells in order when ``seeds`` is None); no softmax (gnn.py:66-68)."""
+                seeds: Optional[torch.Tensor] = None, num_neighbors: int = 0,
+                generator: Optional[torch.Generator] = None, nodeflow=None) -> torch.Tensor:
+        """Logits ``[len(seeds), n_classes]`` (all cells in order when ``seeds`` is None); no softmax (gnn.py:66-68).
+
+        ``num_neighbors > 0`` draws a NodeFlow with at most that many in-edges per node (train.py:37-40, seeded by
+        ``generator``); 0 / None = every in-edge, the reference's default and its eval / predict mode."""
         if features is None:
             features = getattr(g, "features", None)
             if features is None:
                 raise ValueError("pass features or set graph.features")
+        if nodeflow is None and num_neighbors:
+            from .sampler import sample_nodeflow
+            cells = (seeds.to(g.device) - self.gene_num) if seeds is not None \
+                else torch.arange(g.num_cells, device=g.device)
+            nodeflow = sample_nodeflow(g, cells, self.n_layers, int(num_neighbors), generator)
+        if nodeflow is not None:
+            return self.linear(self.embed_sampled(g, features, nodeflow))
         return self.linear(self.embed(g, features, seeds))

@@ -1,0 +1,88 @@
+"""Seeded device-side neighbour sampler: the ``num_neighbors > 0`` training mode of the reference
+(``train.py:37-40,71-78``: ``NeighborSampler(expand_factor=num_neighbors, neighbor_type='in', num_hops=n_layers)``).
+
+DGL 0.4.3 semantics restated: a NodeFlow is built backwards from the seed cells; for every node of layer i+1 at most
+``num_neighbors`` of its in-edges are drawn uniformly without replacement - the unit self-loop is one of those edges
+(it was added to the graph explicitly, preprocess_internal.py:213-214) - and ``fn.mean`` then divides by the number
+of DRAWN edges.  Layer i is the set of sources of the drawn edges.
+
+Here a drawn block is a small destination-major CSR over the *global* source ids (no node relabelling: the source
+tables stay full-size), so it runs through the same K1 / K2 / K3 kernels as the full graph.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+
+from .graph import AggCsr, CellGeneGraph, build_plan
+
+
+@dataclass
+class SampledBlock:
+    rows: torch.Tensor          # int64 [n]  destination ids (cell index or gene index) in NodeFlow order
+    csr: AggCsr                 # n rows; cols = global ids of the other node type; inv_deg = 1 / #drawn edges
+    self_drawn: torch.Tensor    # float32 [n] 1.0 where the self-loop edge was drawn
+
+
+def sample_block(csr: AggCsr, rows: torch.Tensor, k: int, gen: Optional[torch.Generator]) -> SampledBlock:
+    """Draw min(k, deg+1) of the deg+1 in-edges (deg real edges + the self-loop) of every row in ``rows``."""
+    dev = csr.device
+    rows = rows.to(dev).long()
+    n = rows.shape[0]
+    rp = csr.rowptr.long()
+    beg, deg = rp[rows], rp[rows + 1] - rp[rows]
+    cand = deg + 1                                              # + the self-loop
+    off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(cand, 0, out=off[1:])
+    total = int(off[-1])
+    owner = torch.repeat_interleave(torch.arange(n, device=dev), cand)
+    pos = torch.arange(total, device=dev) - off[owner]         # 0..deg ; pos == deg is the self-loop
+    key = torch.rand(total, device=dev, generator=gen, dtype=torch.float64)
+    order = torch.sort(owner.double() + key).indices           # random order inside every row
+    rank = torch.empty(total, dtype=torch.int64, device=dev)
+    rank[order] = torch.arange(total, device=dev) - off[owner[order]]
+    keep = rank < k
+    is_self = pos == deg[owner]
+    self_drawn = torch.zeros(n, dtype=torch.float32, device=dev)
+    self_drawn[owner[keep & is_self]] = 1.0
+    real = keep & ~is_self
+    m_real = torch.bincount(owner[real], minlength=n)
+    rowptr = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(m_real, 0, out=rowptr[1:])
+    eidx = (beg[owner] + pos)[real]                            # edge positions in the parent CSR (row-major, ascending)
+    inv = 1.0 / (m_real.float() + self_drawn).clamp(min=1.0)
+    rowptr32 = rowptr.to(torch.int32)
+    host = rowptr32.cpu().numpy()
+    sub = AggCsr(rowptr32, csr.col[eidx].contiguous(), csr.val[eidx].contiguous(), inv.contiguous(), n, csr.n_cols,
+                 build_plan(host, csr.plan.chunk, device=dev), host)
+    return SampledBlock(rows, sub, self_drawn)
+
+
+@dataclass
+class NodeFlow:
+    """blocks[i] = (cell block, gene block or None) feeding layer i+1; layer sets are implied by the blocks."""
+    blocks: List[Tuple[SampledBlock, Optional[SampledBlock]]]
+
+
+def sample_nodeflow(g: CellGeneGraph, seed_cells: torch.Tensor, n_layers: int, k: int,
+                    gen: Optional[torch.Generator] = None) -> NodeFlow:
+    """``seed_cells``: cell indices (0-based, i.e. node id - G) in the order the logits are wanted."""
+    dev = g.device
+    cells = seed_cells.to(dev).long()
+    genes = torch.empty(0, dtype=torch.int64, device=dev)
+    blocks: List[Tuple[SampledBlock, Optional[SampledBlock]]] = []
+    for _ in range(n_layers):
+        cb = sample_block(g.cg, cells, k, gen)
+        gb = sample_block(g.gc, genes, k, gen) if genes.numel() else None
+        blocks.insert(0, (cb, gb))
+        # next (lower) layer: sources of the drawn edges, plus nodes whose self-loop was drawn
+        new_genes = [cb.csr.col.long()]
+        new_cells = [cells[cb.self_drawn > 0]]
+        if gb is not None:
+            new_cells.append(gb.csr.col.long())
+            new_genes.append(genes[gb.self_drawn > 0])
+        genes = torch.unique(torch.cat(new_genes))
+        cells = torch.unique(torch.cat(new_cells))
+    return NodeFlow(blocks)

@@ -83,3 +83,20 @@ def test_fit_predict_roundtrip(tmp_path):
     out2 = sda.DeepSortPredictor("mouse", "Demo").predict(dt, model_path=tmp_path / "bundle")
     assert out2["cell_type"].tolist() == out["cell_type"].tolist()
     assert (tmp_path / "result").exists()
+
+
+@pytest.mark.gpu
+def test_fit_with_neighbour_subsampling(tmp_path):
+    """num_neighbors > 0 (docs/api.rst:62, train.py:37-40): training draws <= k in-edges per node per batch,
+    evaluation still uses the full neighbourhood (train.py:92-108)."""
+    rng = np.random.default_rng(2)
+    genes = [f"G{i}" for i in range(90)]
+    programs = [np.zeros(90) for _ in range(3)]
+    for t in range(3):
+        programs[t][t * 30:(t + 1) * 30] = 1.0
+    d1, c1, _ = _write_dataset(tmp_path, "mouse_Demo1", 300, rng, genes, programs)
+    clf = sda.DeepSortClassifier("mouse", "Demo", dense_dim=16, hidden_dim=12, batch_size=64, n_epochs=60, n_layers=2,
+                                 learning_rate=0.01, random_seed=3, gpu_id=0, dropout=0.0, num_neighbors=8)
+    clf.fit([(d1, c1)])
+    assert clf.num_neighbors == 8
+    assert max(h["val_acc"] for h in clf.history) > 0.8

@@ -391,3 +391,78 @@ def test_tiled_backward_kernels_match_rowwave():
         ops.TILED_MIN_WORK = old
     for a, b, tol in zip(res["row"], res["tiled"], (2e-5, 2e-3, 2e-5, 2e-4, 2e-4)):
         assert (a - b).abs().max().item() <= tol * max(1.0, a.abs().max().item())
+
+
+# ------------------------------------------------------------------------------------------------
+# neighbour-subsampled NodeFlows (train.py:37-40, num_neighbors > 0)
+def _picker_from(nf, G):
+    """{(block, parent id): drawn source parent ids} from a product NodeFlow, for the oracle to replay."""
+    table = {}
+    for b, (cb, gb) in enumerate(nf.blocks):
+        for blk, is_cell in ((cb, True), (gb, False)):
+            if blk is None:
+                continue
+            rows = blk.rows.cpu().numpy()
+            rp = blk.csr.rowptr.cpu().numpy()
+            col = blk.csr.col.cpu().numpy().astype(np.int64)
+            sd = blk.self_drawn.cpu().numpy()
+            for j, r in enumerate(rows):
+                me = int(r) + (G if is_cell else 0)
+                src = col[rp[j]:rp[j + 1]] + (0 if is_cell else G)
+                table[(b, me)] = np.concatenate([src, [me]]) if sd[j] > 0 else src
+    return lambda block, v: table[(block, v)]
+
+
+@pytest.mark.parametrize("k", [1, 3, 8])
+def test_sampled_nodeflow_matches_oracle_on_same_sample(k):
+    from scdeepsort_amd.sampler import sample_nodeflow
+    c = small_case(cells=90, genes=40, dim=16, hidden=12, n_classes=4, seed=31, test_cells=0)
+    G = c["G"]
+    sd = O.init_params(16, 12, 4, 2, G, seed=8)
+    sd["alpha"] = sd["alpha"] + 0.1 * torch.randn_like(sd["alpha"])
+    rg = O.build_reference_graph(c["expr"])
+    g = sda.CellGeneGraph.from_expression(c["expr"], device=DEV)
+    m = make_model(sd, 16, 12, 4, 2, G).train()
+    seeds = np.array([G + i for i in (4, 0, 17, 63, 88, 3, 41)])
+    labels = torch.tensor([0, 1, 2, 3, 1, 0, 2])
+    gen = torch.Generator(device=DEV); gen.manual_seed(100 + k)
+    nf = sample_nodeflow(g, torch.from_numpy(seeds - G), 2, k, gen)
+    # drawn edge count per node = min(k, in-degree incl. self-loop)
+    for cb, gb in nf.blocks:
+        for blk, parent in ((cb, g.cg), (gb, g.gc)):
+            if blk is None:
+                continue
+            full = (parent.rowptr[1:] - parent.rowptr[:-1]).long()[blk.rows] + 1
+            drawn = (blk.csr.rowptr[1:] - blk.csr.rowptr[:-1]).long() + blk.self_drawn.long()
+            assert torch.equal(drawn, torch.clamp(full, max=k))
+    logits = m(g, dev(c["feats"]), nodeflow=nf)
+    loss = F.cross_entropy(logits, labels.to(DEV), reduction="sum")
+    loss.backward()
+    osd = {n: t.clone().requires_grad_(True) for n, t in sd.items()}
+    want = O.nodeflow_forward(osd, rg, torch.from_numpy(c["feats"]), seeds, 2, picker=_picker_from(nf, G))
+    oloss = F.cross_entropy(want, labels, reduction="sum")
+    oloss.backward()
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), want.detach().numpy(), atol=TOL)
+    for n, p in m.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), osd[n].grad.numpy(), atol=TOL * max(1.0, float(osd[n].grad.abs().max())),
+                                   err_msg=n)
+
+
+def test_sampled_nodeflow_properties():
+    c = small_case(seed=32)
+    G = c["G"]
+    sd = O.init_params(c["dim"], c["hidden"], c["n_classes"], 2, G, seed=9)
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
+    m = make_model(sd, c["dim"], c["hidden"], c["n_classes"], 2, G)
+    x = dev(c["feats"])
+    seeds = torch.arange(G, G + c["C"], device=DEV)[::3]
+    with torch.no_grad():
+        full = m(g, x, seeds=seeds)
+        # expand_factor >= every in-degree: the NodeFlow is the full neighbourhood (train.py:37-38)
+        big = m(g, x, seeds=seeds, num_neighbors=10 ** 6, generator=torch.Generator(device=DEV).manual_seed(1))
+        a = m(g, x, seeds=seeds, num_neighbors=4, generator=torch.Generator(device=DEV).manual_seed(7))
+        b = m(g, x, seeds=seeds, num_neighbors=4, generator=torch.Generator(device=DEV).manual_seed(7))
+        d = m(g, x, seeds=seeds, num_neighbors=4, generator=torch.Generator(device=DEV).manual_seed(8))
+    np.testing.assert_allclose(big.cpu().numpy(), full.cpu().numpy(), atol=TOL)
+    assert torch.equal(a, b)                      # same seed, same draw
+    assert not torch.equal(a, d)

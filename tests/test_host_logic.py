@@ -68,3 +68,59 @@ def test_shard_ranges_cover_cells():
             assert b == c and b >= a
         sizes = [b - a for a, b in spans]
         assert max(sizes) - min(sizes) <= 1
+
+
+def _cpu_csr(n_rows=60, n_cols=45, seed=0):
+    """A destination-major AggCsr on CPU tensors (the sampler is pure index work + the host plan builder)."""
+    from scdeepsort_amd.graph import AggCsr, build_plan
+    rng = np.random.default_rng(seed)
+    dense = rng.random((n_rows, n_cols)) < 0.25
+    dense[2] = False                                    # an isolated row: only its self-loop can be drawn
+    dense[7] = True                                     # a hub row
+    rowptr = np.concatenate([[0], np.cumsum(dense.sum(1))]).astype(np.int32)
+    col = np.nonzero(dense)[1].astype(np.int32)
+    val = rng.random(len(col)).astype(np.float32)
+    inv = (1.0 / (dense.sum(1) + 1)).astype(np.float32)
+    return AggCsr(torch.from_numpy(rowptr), torch.from_numpy(col), torch.from_numpy(val), torch.from_numpy(inv),
+                  n_rows, n_cols, build_plan(rowptr), rowptr), dense
+
+
+def test_neighbour_sampler_draw_counts_and_membership():
+    """train.py:37-40: at most num_neighbors in-edges per node, uniform without replacement, self-loop included."""
+    from scdeepsort_amd.sampler import sample_block
+    csr, dense = _cpu_csr()
+    rows = torch.tensor([7, 2, 0, 33, 59, 12])
+    gen = torch.Generator().manual_seed(3)
+    for k in (1, 2, 5, 100):
+        blk = sample_block(csr, rows, k, gen)
+        rp = blk.csr.rowptr.numpy()
+        for j, r in enumerate(rows.tolist()):
+            got = blk.csr.col.numpy()[rp[j]:rp[j + 1]]
+            full = np.nonzero(dense[r])[0]
+            assert len(set(got)) == len(got) and set(got) <= set(full)
+            n_drawn = len(got) + int(blk.self_drawn[j])
+            assert n_drawn == min(k, len(full) + 1)
+            assert abs(float(blk.csr.inv_deg[j]) - 1.0 / n_drawn) < 1e-7
+            # weights travel with their edge
+            pos = {c: csr.val.numpy()[csr.rowptr_host[r] + i] for i, c in enumerate(full)}
+            np.testing.assert_array_equal(blk.csr.val.numpy()[rp[j]:rp[j + 1]], [pos[c] for c in got])
+    blk = sample_block(csr, rows, 100, gen)             # k >= every degree: the whole neighbourhood
+    assert torch.all(blk.self_drawn == 1)
+
+
+def test_neighbour_sampler_is_uniform_and_seeded():
+    from scdeepsort_amd.sampler import sample_block
+    csr, dense = _cpu_csr(seed=1)
+    rows = torch.tensor([7])                            # hub row: 45 edges + self-loop = 46 candidates
+    gen = torch.Generator().manual_seed(11)
+    hits = np.zeros(46)
+    n = 4000
+    for _ in range(n):
+        blk = sample_block(csr, rows, 5, gen)
+        hits[blk.csr.col.numpy()] += 1
+        hits[45] += float(blk.self_drawn[0])
+    p = 5 / 46
+    assert np.all(np.abs(hits / n - p) < 5 * np.sqrt(p * (1 - p) / n))
+    a = sample_block(csr, rows, 5, torch.Generator().manual_seed(5))
+    b = sample_block(csr, rows, 5, torch.Generator().manual_seed(5))
+    assert torch.equal(a.csr.col, b.csr.col) and torch.equal(a.self_drawn, b.self_drawn)

@@ -140,3 +140,31 @@ def test_postprocess_unsure_rule():
     assert pred[1] == -1
     pred0, _ = O.postprocess(logits, unsure_rate=0.0)
     assert (pred0 >= 0).all()
+
+
+def test_sampled_nodeflow_replay_matches_rng_draw():
+    """num_neighbors > 0 (train.py:37-40): replaying a recorded draw through ``picker`` reproduces the rng result,
+    and a draw no smaller than every in-degree is the full neighbourhood."""
+    c = small_case(seed=21)
+    sd = O.init_params(c["dim"], c["hidden"], c["n_classes"], 2, c["G"], seed=2)
+    rg = O.build_reference_graph(c["expr"], c["support_mask"])
+    x = torch.from_numpy(c["feats"])
+    seeds = np.arange(c["G"], c["G"] + 20)
+    full = O.nodeflow_forward(sd, rg, x, seeds, 2)
+    big = O.nodeflow_forward(sd, rg, x, seeds, 2, num_neighbors=10 ** 6, rng=np.random.default_rng(0))
+    assert torch.equal(full, big)
+    ine = O._InEdges(rg)
+    rec = {}
+    rng = np.random.default_rng(4)
+
+    def recording(block, v):
+        lo, hi = ine.ptr[v], ine.ptr[v + 1]
+        sel = np.arange(lo, hi)
+        if hi - lo > 3:
+            sel = rng.choice(sel, size=3, replace=False)
+        rec[(block, v)] = ine.src[sel]
+        return rec[(block, v)]
+    a = O.nodeflow_forward(sd, rg, x, seeds, 2, picker=recording)
+    b = O.nodeflow_forward(sd, rg, x, seeds, 2, picker=lambda blk, v: rec[(blk, v)])
+    assert torch.equal(a, b)
+    assert not torch.allclose(a, full)
