@@ -14,6 +14,7 @@ PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
 SRC = [PKG / "csrc" / "wgnn_kernels.hip", PKG / "csrc" / "wgnn_tiled.hip"]
 LIB = PKG / "libwgnn_hip.so"
+GEN = PKG / "csrc" / "gen_flat_asm.py"          # writes csrc/wgnn_flat_asm.inc (the hand-scheduled entry pipeline)
 
 
 def hipcc() -> str:
@@ -26,13 +27,15 @@ def hipcc() -> str:
 def needs_build() -> bool:
     if not LIB.exists():
         return True
-    deps = SRC + [ROOT / "include" / "wgnn.h"] + sorted((PKG / "csrc").glob("*.h*"))
+    deps = SRC + [ROOT / "include" / "wgnn.h", GEN] + sorted((PKG / "csrc").glob("*.h*")) + sorted((PKG / "csrc").glob("*.inc"))
     return any(d.stat().st_mtime > LIB.stat().st_mtime for d in deps if d.exists())
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not needs_build():
         return LIB
+    import runpy
+    runpy.run_path(str(GEN))["main"](str(PKG / "csrc" / "wgnn_flat_asm.inc"))
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
            "-Wno-pass-failed", "-Wno-inline-asm", f"-I{ROOT / 'include'}", *map(str, SRC), "-o", str(LIB)]
     if verbose:

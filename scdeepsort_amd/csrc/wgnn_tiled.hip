@@ -20,6 +20,7 @@
 // expressed in ~every cell) are split across workgroups; their partial sums are folded by
 // agg_finalize in a fixed order (deterministic, no atomics).
 #include "wgnn_common.h"
+#include "wgnn_flat_asm.inc"
 
 namespace {
 using namespace wgnn;
@@ -324,6 +325,101 @@ agg_tiled_flat(const KArgs a, const TArgs t) {
 }
 
 template <typename TOut, int EPI>
+__global__ void __launch_bounds__(kTW * 64) __attribute__((amdgpu_num_vgpr(44), amdgpu_num_sgpr(80)))
+agg_tiled_flat4(const KArgs a, const TArgs t) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int row_bytes = 1024;
+    const int kKB = t.kb, buf_bytes = kKB * row_bytes;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tile = blockIdx.x;
+    const int2 hdr = t.tile_hdr[tile];
+    const int cb = __builtin_amdgcn_readfirstlane(hdr.x), ce = __builtin_amdgcn_readfirstlane(hdr.y);
+    const int nblk = (ce - cb + kKB - 1) / kKB;
+    cptr_t seg = (cptr_t)(t.seg_ptr + ((size_t)tile * t.nblk_max) * kTW + wave);
+    const bool do_fill = !(a.flags & kDbgNoFill), do_comp = !(a.flags & kDbgNoCompute);
+
+    for (int r = 0; r < kRPW; ++r)                       // zero the accumulators v[64:127]
+        asm volatile("s_set_gpr_idx_on %0, gpr_idx(DST)\n\tv_mov_b32 v64, 0\n\tv_mov_b32 v65, 0\n\t"
+                     "v_mov_b32 v66, 0\n\tv_mov_b32 v67, 0\n\ts_set_gpr_idx_off" ::"s"(r * 4) : WGNN_CLOB);
+
+    auto fill = [&](int b, int buf) {
+        const int r0 = cb + b * kKB;
+        const int nbytes = min(kKB, ce - r0) * row_bytes;
+        const char* g = reinterpret_cast<const char*>(a.src) + (size_t)r0 * row_bytes;
+        char* l = smem + buf * buf_bytes;
+        for (int p = wave; p * 1024 < nbytes; p += kTW)
+            __builtin_amdgcn_global_load_lds((gptr_t)(g + p * 1024 + lane * 16), (lptr_t)(l + p * 1024), 16, 0, 0);
+    };
+    // RIGHT-aligned chunk: with n = min(64, e - s) entries, lane j <- entry s + j - (64 - n); the lanes in front of
+    // the chunk replicate its first entry (consume() zeroes their weight).  Nothing here touches the loaded value,
+    // so the load stays in flight until the next block.
+    auto load_chunk = [&](int s, int e, int2& ent) {
+        ent = make_int2(0, 0);
+        if (s < e) ent = t.entries[max(s + lane - (64 - min(64, e - s)), s)];
+    };
+    // n (1..64) entries of one chunk -> the generated straight-line pipeline (gen_flat_asm.py)
+    auto consume = [&](const int2& ent, int n, const char* lbuf) {
+        const int pk = ((ent.x & 0xFF) << 18) | ((ent.x >> 8) << 2);       // (src_local*1024)<<8 | 4*slot
+        const int wv = lane >= 64 - n ? ent.y : 0;                         // padding lanes: weight 0
+        const int lbase = (int)(size_t)lbuf;                               // LDS byte address of this lane's slice
+        const int m = (n + 1) >> 1;
+        asm volatile(WGNN_FLAT4_ASM ::[pk] "v"(pk), [wv] "v"(wv), [lb] "v"(lbase), [m] "s"(m)
+                     : "m0", "memory", "scc", "v44", "v45", "v48", "v63", "v64", "v127", "s80", "s81", "s82", "s83", "s84",
+                       "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95");
+    };
+    auto block = [&](int b, int& cs, int& ce0, const int2& cur0, int ns, int ne, int2& nxt0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my DMA pieces of block b and my entry chunk have landed
+        if (!(a.flags & kDbgNoBarrier)) __syncthreads();      // everyone's have; everyone is done with block b-1
+        asm volatile("" ::"s"(ns), "s"(ne));                  // retire the scalar loads issued at the end of block b-1
+        if (b + 1 < nblk) {
+            load_chunk(ns, ne, nxt0);
+            if (do_fill) fill(b + 1, (b + 1) & 1);
+        }
+        const int cs_ = cs, ce_ = ce0;
+        const char* lbuf = smem + (b & 1) * buf_bytes + lane * 16;
+        int q = 0;
+        for (int s = cs_; s < ce_ && do_comp; s += 64, ++q) {
+            int2 ent = cur0;
+            if (q >= 1) load_chunk(s, ce_, ent);              // rare: more than 64 entries for this wave in one block
+            consume(ent, min(64, ce_ - s), lbuf);
+        }
+        asm volatile("" ::: "memory");
+        if (b + 2 < nblk) { cs = seg[(b + 2) * kTW]; ce0 = seg[(b + 2) * kTW + 1]; }
+    };
+
+    if (nblk > 0) {
+        int sA = seg[0], eA = seg[1], sB = 0, eB = 0;
+        if (nblk > 1) { sB = seg[kTW]; eB = seg[kTW + 1]; }
+        int2 a0, b0;
+        load_chunk(sA, eA, a0);
+        b0 = make_int2(0, 0);
+        if (do_fill) fill(0, 0);
+        for (int b = 0; b < nblk; b += 2) {
+            block(b, sA, eA, a0, sB, eB, b0);
+            if (b + 1 < nblk) block(b + 1, sB, eB, b0, sA, eA, a0);
+        }
+    }
+
+    const int4* __restrict__ items = t.tile_items + (size_t)tile * kTileRows + wave * kRPW;
+    for (int i = 0; i < kRPW; ++i) {
+        const int4 it = items[i];
+        const int slot = __builtin_amdgcn_readfirstlane(it.x), pslot = __builtin_amdgcn_readfirstlane(it.w);
+        if (slot < 0) continue;
+        float4 v;
+        asm volatile("s_set_gpr_idx_on %4, gpr_idx(SRC0)\n\tv_mov_b32 %0, v64\n\tv_mov_b32 %1, v65\n\t"
+                     "v_mov_b32 %2, v66\n\tv_mov_b32 %3, v67\n\ts_set_gpr_idx_off"
+                     : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w) : "s"(i * 4) : "m0");
+        if (pslot >= 0) {
+            st4(a.partials + (size_t)pslot * a.D + lane * 4, v);
+        } else {
+            float4 one[1] = {v};
+            epilogue<64, 1, float, TOut, EPI>(a, one, slot, lane, true);
+        }
+    }
+}
+
+template <typename TOut, int EPI>
 int launch_tiled(const KArgs& a, const TArgs& t, long n_tiles, hipStream_t st) {
     const int lds = 2 * t.kb * a.D * (int)sizeof(float);
     static int configured = 0;                       // per instantiation
@@ -340,9 +436,16 @@ int launch_tiled(const KArgs& a, const TArgs& t, long n_tiles, hipStream_t st) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_tiled_flat<TOut, EPI>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
                 return WGNN_ERR_LAUNCH;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_tiled_flat4<TOut, EPI>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+                return WGNN_ERR_LAUNCH;
             flat_configured = lds;
         }
-        hipLaunchKernelGGL((agg_tiled_flat<TOut, EPI>), dim3((unsigned)n_tiles), dim3(kTW * 64), lds, st, a, t);
+        if (a.flags & (1u << 20)) {                    // bit 20: previous (compiler-scheduled loop) flat kernel, for A/B timing
+            hipLaunchKernelGGL((agg_tiled_flat<TOut, EPI>), dim3((unsigned)n_tiles), dim3(kTW * 64), lds, st, a, t);
+        } else {
+            hipLaunchKernelGGL((agg_tiled_flat4<TOut, EPI>), dim3((unsigned)n_tiles), dim3(kTW * 64), lds, st, a, t);
+        }
     } else {
         hipLaunchKernelGGL((agg_tiled<TOut, EPI>), dim3((unsigned)n_tiles), dim3(kTW * 64), lds, st, a, t);
     }
