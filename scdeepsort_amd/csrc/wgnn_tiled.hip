@@ -19,6 +19,7 @@
 // reference's own multiply order, (h*alpha)*w.  Tiles carry a column range so that hub rows (genes
 // expressed in ~every cell) are split across workgroups; their partial sums are folded by
 // agg_finalize in a fixed order (deterministic, no atomics).
+#include <type_traits>
 #include "wgnn_common.h"
 #include "wgnn_flat_asm.inc"
 
@@ -29,6 +30,7 @@ constexpr int kTW = 16;                       // waves per tile workgroup
 constexpr int kRPW = 16;                      // destination rows per wave
 constexpr int kKBDefault = 64;                // source rows per LDS block (TArgs::kb; 2*kb*D*4 B of LDS)
 constexpr int kTileRows = kTW * kRPW;         // 256
+constexpr int kWStripBytes = kTW * 256;       // flat kernel: one 64-entry weight strip per wave
 // ablation switches (timing experiments only; results are wrong when set)
 constexpr unsigned kDbgNoFill = 1u << 16, kDbgNoCompute = 1u << 17, kDbgNoBarrier = 1u << 18;
 
@@ -324,8 +326,31 @@ agg_tiled_flat(const KArgs a, const TArgs t) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// agg_tiled_flat4: same tile / block structure, but (a) the per-entry loop is the generated straight-line pipeline of
+// gen_flat_asm.py and (b) EVERY vector-memory operation of the block loop - entry-chunk loads, segment loads, the
+// global->LDS DMA - is issued from inline asm into literal registers, with hand-counted s_waitcnt.  The compiler
+// otherwise protects each VGPR load result / LDS access with `s_waitcnt vmcnt(0)` placed AFTER the next block's DMA
+// has been issued, which serialises fill and compute.
+//   v[32:33] segment {begin, end} of block b+3 ; v[34:35], v[36:37], v[38:39] entry chunks of blocks b, b+1, b+2 (mod 3)
+// VMEM issue order inside block b:  S(b+3), DMA pieces of block b+1, E(b+2)   =>  at the top of block b+1 everything
+// but E(b+2) must have landed: s_waitcnt vmcnt(1).  An entry chunk therefore has two block times to arrive.
+// ---------------------------------------------------------------------------------------------
+template <int SET> __device__ __forceinline__ void chunk_load(const int2* p) {
+    if constexpr (SET == 0) asm volatile("global_load_dwordx2 v[34:35], %0, off" ::"v"(p) : "memory", "v34", "v35");
+    if constexpr (SET == 1) asm volatile("global_load_dwordx2 v[36:37], %0, off" ::"v"(p) : "memory", "v36", "v37");
+    if constexpr (SET == 2) asm volatile("global_load_dwordx2 v[38:39], %0, off" ::"v"(p) : "memory", "v38", "v39");
+}
+template <int SET> __device__ __forceinline__ int2 chunk_get() {
+    int2 e;
+    if constexpr (SET == 0) asm volatile("v_mov_b32 %0, v34\n\tv_mov_b32 %1, v35" : "=v"(e.x), "=v"(e.y)::"memory");
+    if constexpr (SET == 1) asm volatile("v_mov_b32 %0, v36\n\tv_mov_b32 %1, v37" : "=v"(e.x), "=v"(e.y)::"memory");
+    if constexpr (SET == 2) asm volatile("v_mov_b32 %0, v38\n\tv_mov_b32 %1, v39" : "=v"(e.x), "=v"(e.y)::"memory");
+    return e;
+}
+
 template <typename TOut, int EPI>
-__global__ void __launch_bounds__(kTW * 64) __attribute__((amdgpu_num_vgpr(44), amdgpu_num_sgpr(80)))
+__global__ void __launch_bounds__(kTW * 64) __attribute__((amdgpu_num_vgpr(32), amdgpu_num_sgpr(80)))
 agg_tiled_flat4(const KArgs a, const TArgs t) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int row_bytes = 1024;
@@ -336,68 +361,86 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
     const int2 hdr = t.tile_hdr[tile];
     const int cb = __builtin_amdgcn_readfirstlane(hdr.x), ce = __builtin_amdgcn_readfirstlane(hdr.y);
     const int nblk = (ce - cb + kKB - 1) / kKB;
-    cptr_t seg = (cptr_t)(t.seg_ptr + ((size_t)tile * t.nblk_max) * kTW + wave);
+    const int* seg = t.seg_ptr + ((size_t)tile * t.nblk_max) * kTW + wave;     // seg[b*16], seg[b*16+1]
     const bool do_fill = !(a.flags & kDbgNoFill), do_comp = !(a.flags & kDbgNoCompute);
+    const bool do_barrier = !(a.flags & kDbgNoBarrier);
 
     for (int r = 0; r < kRPW; ++r)                       // zero the accumulators v[64:127]
         asm volatile("s_set_gpr_idx_on %0, gpr_idx(DST)\n\tv_mov_b32 v64, 0\n\tv_mov_b32 v65, 0\n\t"
                      "v_mov_b32 v66, 0\n\tv_mov_b32 v67, 0\n\ts_set_gpr_idx_off" ::"s"(r * 4) : WGNN_CLOB);
 
-    auto fill = [&](int b, int buf) {
+    // global -> LDS DMA of source block b into buffer b&1: one 1 KiB row per wave-instruction
+    auto fill = [&](int b) {
         const int r0 = cb + b * kKB;
         const int nbytes = min(kKB, ce - r0) * row_bytes;
-        const char* g = reinterpret_cast<const char*>(a.src) + (size_t)r0 * row_bytes;
-        char* l = smem + buf * buf_bytes;
+        const char* g = reinterpret_cast<const char*>(a.src) + (size_t)r0 * row_bytes + lane * 16;
+        const int l = (int)(size_t)smem + (b & 1) * buf_bytes;
         for (int p = wave; p * 1024 < nbytes; p += kTW)
-            __builtin_amdgcn_global_load_lds((gptr_t)(g + p * 1024 + lane * 16), (lptr_t)(l + p * 1024), 16, 0, 0);
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g + p * 1024), "s"(l + p * 1024)
+                         : "m0", "memory");
     };
-    // RIGHT-aligned chunk: with n = min(64, e - s) entries, lane j <- entry s + j - (64 - n); the lanes in front of
-    // the chunk replicate its first entry (consume() zeroes their weight).  Nothing here touches the loaded value,
-    // so the load stays in flight until the next block.
-    auto load_chunk = [&](int s, int e, int2& ent) {
-        ent = make_int2(0, 0);
-        if (s < e) ent = t.entries[max(s + lane - (64 - min(64, e - s)), s)];
+    // RIGHT-aligned entry chunk of segment [s, e): with n = min(64, e - s) entries, lane j <- entry s + j - (64 - n);
+    // the lanes in front of the chunk replicate a valid entry (consume() zeroes their weight).  Always issues exactly
+    // one load (the vmcnt bookkeeping depends on it), also for an empty segment.
+    auto chunk_addr = [&](int s, int e) {
+        const int idx = min(max(s + lane - (64 - min(64, e - s)), s), max(e - 1, 0));
+        return t.entries + idx;
     };
-    // n (1..64) entries of one chunk -> the generated straight-line pipeline (gen_flat_asm.py)
-    auto consume = [&](const int2& ent, int n, const char* lbuf) {
-        const int pk = ((ent.x & 0xFF) << 18) | ((ent.x >> 8) << 2);       // (src_local*1024)<<8 | 4*slot
+    auto seg_load = [&](int b) {                          // -> v[32:33]
+        asm volatile("global_load_dwordx2 v[32:33], %0, off" ::"v"(seg + b * kTW) : "memory", "v32", "v33");
+    };
+    // n (1..64) entries of one chunk -> the generated straight-line pipeline.  The weights go through the wave's
+    // 256-byte LDS strip (behind the two row buffers) and come back as broadcast reads.
+    const int lane16 = lane * 16, row_mask = ~1023;
+    const int wstrip_addr = (int)(size_t)smem + 2 * buf_bytes + wave * 256;
+    const int wlane_addr = wstrip_addr + lane * 4;
+    auto consume = [&](const int2& ent, int n, int buf_addr) {
+        const int pk = (buf_addr + ((ent.x & 0xFF) << 10)) | ((ent.x >> 8) << 2);   // LDS address of the source row | 4*slot
         const int wv = lane >= 64 - n ? ent.y : 0;                         // padding lanes: weight 0
-        const int lbase = (int)(size_t)lbuf;                               // LDS byte address of this lane's slice
         const int m = (n + 1) >> 1;
-        asm volatile(WGNN_FLAT4_ASM ::[pk] "v"(pk), [wv] "v"(wv), [lb] "v"(lbase), [m] "s"(m)
-                     : "m0", "memory", "scc", "v44", "v45", "v48", "v63", "v64", "v127", "s80", "s81", "s82", "s83", "s84",
-                       "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95");
+        asm volatile("ds_write_b32 %[wa], %[wv]\n\t" WGNN_FLAT4_ASM
+                     ::[pk] "v"(pk), [wa] "v"(wlane_addr), [wv] "v"(wv), [wb] "v"(wstrip_addr), [lb] "v"(lane16),
+                       [mk] "v"(row_mask), [m] "s"(m)
+                     : "m0", "memory", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v48", "v63", "v64", "v127",
+                       "s80", "s81", "s82", "s83", "s84", "s85", "s92", "s94", "s95");
     };
-    auto block = [&](int b, int& cs, int& ce0, const int2& cur0, int ns, int ne, int2& nxt0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my DMA pieces of block b and my entry chunk have landed
-        if (!(a.flags & kDbgNoBarrier)) __syncthreads();      // everyone's have; everyone is done with block b-1
-        asm volatile("" ::"s"(ns), "s"(ne));                  // retire the scalar loads issued at the end of block b-1
-        if (b + 1 < nblk) {
-            load_chunk(ns, ne, nxt0);
-            if (do_fill) fill(b + 1, (b + 1) & 1);
+    // one source block.  CUR / NXT = register sets of blocks b / b+2; (cs, ce0) = this block's segment; (ns, ne) receive
+    // the segment of block b+2 (kept in SGPRs until that block is consumed).
+    auto block = [&](auto cur_set, auto nxt_set, int b, int cs, int ce0, int& ns, int& ne) {
+        constexpr int CUR = decltype(cur_set)::value, NXT = decltype(nxt_set)::value;
+        if (b + 1 < nblk) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");    // all but E(b+1): DMA of block b, E(b), S(b+2)
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (do_barrier) __builtin_amdgcn_s_barrier();       // everyone's DMA pieces landed; everyone is done with block b-1
+        if (b + 2 < nblk) {
+            asm volatile("v_readfirstlane_b32 %0, v32\n\tv_readfirstlane_b32 %1, v33" : "=s"(ns), "=s"(ne)::"memory");
+            if (b + 3 < nblk) seg_load(b + 3);
         }
-        const int cs_ = cs, ce_ = ce0;
-        const char* lbuf = smem + (b & 1) * buf_bytes + lane * 16;
-        int q = 0;
-        for (int s = cs_; s < ce_ && do_comp; s += 64, ++q) {
-            int2 ent = cur0;
-            if (q >= 1) load_chunk(s, ce_, ent);              // rare: more than 64 entries for this wave in one block
-            consume(ent, min(64, ce_ - s), lbuf);
+        if (b + 1 < nblk && do_fill) fill(b + 1);
+        if (b + 2 < nblk) chunk_load<NXT>(chunk_addr(ns, ne));
+        const int buf_addr = (int)(size_t)smem + (b & 1) * buf_bytes;         // 1 KiB-aligned: smem is the only LDS object
+        if (do_comp && cs < ce0) {
+            consume(chunk_get<CUR>(), min(64, ce0 - cs), buf_addr);
+            for (int s = cs + 64; s < ce0; s += 64) {        // rare: more than 64 entries for this wave in one block
+                chunk_load<CUR>(chunk_addr(s, ce0));        // (E(b+2) is in flight behind it: wait for both)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                consume(chunk_get<CUR>(), min(64, ce0 - s), buf_addr);
+            }
         }
-        asm volatile("" ::: "memory");
-        if (b + 2 < nblk) { cs = seg[(b + 2) * kTW]; ce0 = seg[(b + 2) * kTW + 1]; }
     };
 
     if (nblk > 0) {
-        int sA = seg[0], eA = seg[1], sB = 0, eB = 0;
-        if (nblk > 1) { sB = seg[kTW]; eB = seg[kTW + 1]; }
-        int2 a0, b0;
-        load_chunk(sA, eA, a0);
-        b0 = make_int2(0, 0);
-        if (do_fill) fill(0, 0);
-        for (int b = 0; b < nblk; b += 2) {
-            block(b, sA, eA, a0, sB, eB, b0);
-            if (b + 1 < nblk) block(b + 1, sB, eB, b0, sA, eA, a0);
+        using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>; using S2 = std::integral_constant<int, 2>;
+        cptr_t sseg = (cptr_t)seg;                        // the first two segments through the scalar cache
+        int sA = sseg[0], eA = sseg[1], sB = 0, eB = 0, sC = 0, eC = 0;
+        if (nblk > 1) { sB = sseg[kTW]; eB = sseg[kTW + 1]; }
+        if (nblk > 2) seg_load(2);
+        if (do_fill) fill(0);
+        chunk_load<0>(chunk_addr(sA, eA));
+        if (nblk > 1) chunk_load<1>(chunk_addr(sB, eB));
+        for (int b = 0; b < nblk; b += 3) {                  // unrolled by three: the register sets rotate statically
+            block(S0{}, S2{}, b, sA, eA, sC, eC);
+            if (b + 1 < nblk) block(S1{}, S0{}, b + 1, sB, eB, sA, eA);
+            if (b + 2 < nblk) block(S2{}, S1{}, b + 2, sC, eC, sB, eB);
         }
     }
 
@@ -421,7 +464,7 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
 
 template <typename TOut, int EPI>
 int launch_tiled(const KArgs& a, const TArgs& t, long n_tiles, hipStream_t st) {
-    const int lds = 2 * t.kb * a.D * (int)sizeof(float);
+    const int lds = 2 * t.kb * a.D * (int)sizeof(float) + (a.D == 256 ? kWStripBytes : 0);
     static int configured = 0;                       // per instantiation
     if (configured < lds) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_tiled<TOut, EPI>),
@@ -473,7 +516,8 @@ extern "C" int wgnn_agg_fwd_tiled(const int32_t* rowptr, const float* alpha, int
     if (!inv_deg && !rowptr && !(flags & WGNN_FLAG_NO_MEAN)) return WGNN_ERR_BAD_ARG;
     if (D <= 0 || D % 4 || ld_out % 4 || (h_self && ld_self % 4)) return WGNN_ERR_ALIGNMENT;
     if (D > 256) return WGNN_ERR_UNSUPPORTED;                     // one float4 per lane
-    if (block_rows < 16 || block_rows > 255 || 2 * (int64_t)block_rows * D * 4 > 160 * 1024) return WGNN_ERR_PLAN;
+    if (block_rows < 16 || block_rows > 255 || 2 * (int64_t)block_rows * D * 4 + (D == 256 ? kWStripBytes : 0) > 160 * 1024)
+        return WGNN_ERR_PLAN;
     if (!aligned16(h_src) || !aligned16(out) || (h_self && !aligned16(h_self)) || (bias && !aligned16(bias)))
         return WGNN_ERR_ALIGNMENT;
     if (n_tiles > 0 && (!tile_items || !tile_hdr || !entries || !seg_ptr)) return WGNN_ERR_BAD_ARG;
@@ -508,7 +552,8 @@ static int tiled_common_check(int32_t D, int32_t block_rows, const void* entries
                               const float* partials, int64_t n_partials) {
     if (D <= 0 || D % 4) return WGNN_ERR_ALIGNMENT;
     if (D > 256) return WGNN_ERR_UNSUPPORTED;
-    if (block_rows < 16 || block_rows > 255 || 2 * (int64_t)block_rows * D * 4 > 160 * 1024) return WGNN_ERR_PLAN;
+    if (block_rows < 16 || block_rows > 255 || 2 * (int64_t)block_rows * D * 4 + (D == 256 ? kWStripBytes : 0) > 160 * 1024)
+        return WGNN_ERR_PLAN;
     if (n_tiles < 0 || (n_tiles > 0 && (!tile_items || !tile_hdr || !entries || !seg_ptr))) return WGNN_ERR_BAD_ARG;
     if (n_long > 0 && (!long_rows || !partials || n_partials <= 0)) return WGNN_ERR_WORKSPACE;
     return WGNN_OK;

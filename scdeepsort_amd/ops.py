@@ -198,8 +198,9 @@ def agg_bwd_alpha(csr: AggCsr, g: torch.Tensor, h_src: torch.Tensor, h_self: Opt
 
 
 def tiled_block_rows(D: int) -> int:
-    """Source rows per LDS block: 80 x 1 KiB x 2 buffers = all 160 KiB of a CU at D = 256 (measured best), else 64."""
-    return 80 if D == 256 else 64
+    """Source rows per LDS block: at D = 256, 78 x 1 KiB x 2 buffers + the 4 KiB of per-wave weight strips = all
+    160 KiB of a CU (measured best); else 64."""
+    return 78 if D == 256 else 64
 
 
 def agg_fwd_tiled(csr: AggCsr, tplan, alpha: Optional[torch.Tensor], mode: int, self_idx: int,

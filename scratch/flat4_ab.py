@@ -14,7 +14,7 @@ def timeit(f,n=5):
     f(); torch.cuda.synchronize(); t=time.perf_counter()
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.perf_counter()-t)/n*1e3
-kb=80
+kb=int(sys.argv[2]) if len(sys.argv) > 2 else 78
 tpc=g.cg.tile_plan(kb); tpg=g.gc.tile_plan(kb)
 res={}
 for nm,fl in [('flat3',1<<20),('flat4',0)]:
