@@ -31,16 +31,37 @@ import sys
 
 N_PAIRS = 32
 ABLATE = set(filter(None, os.environ.get("WGNN_GEN_ABLATE", "").split(",")))   # timing experiments only (wrong results)
-XREG = {0: (48, 52), 1: (56, 60)}          # staging buffers by pair parity: first regs of entry 0 / entry 1
+DEPTH = int(os.environ.get("WGNN_GEN_DEPTH", "1"))      # LDS reads are issued DEPTH steps ahead of their FMAs
+XREGS = [(48, 52), (56, 60), (96, 100)]    # staging buffers, first regs of entry 0 / entry 1 (third: DEPTH=2 experiment)
+WREGS = [40, 42, 104]
+
+
+def xreg(p):
+    return XREGS[p % (DEPTH + 1)]
 
 
 def sset(p):
-    base = 80 + 2 * (p % 3)
+    base = 80 + 2 * (p % (DEPTH + 2))
     return dict(pk0=base, pk1=base + 1)
 
 
 def wreg(p):
-    return 40 + 2 * (p % 2)
+    return WREGS[p % (DEPTH + 1)]
+
+
+WRL = "wrl" in ABLATE            # experiment: weights through v_readlane into SGPR pairs instead of the LDS strip
+SCR = 92                         # scratch SGPR of the computed branch
+
+
+def wsgpr(p):
+    base = 84 + 4 * (p % 2)          # (experiment only: overlaps nothing at DEPTH = 1 with 3 pk sets in s80..s85? no: s86+)
+    base = 86 + 4 * (p % 2)
+    return base, base + 2
+
+
+def wreadlanes(p):
+    w0, w1 = wsgpr(p)
+    return [f"v_readlane_b32 s{w0}, %[wv], {2 * p}", f"v_readlane_b32 s{w1}, %[wv], {2 * p + 1}"]
 
 
 def readlanes(p):
@@ -59,10 +80,12 @@ def addresses(p):
 
 
 def reads(p):
-    x0, x1 = XREG[p % 2]
+    x0, x1 = xreg(p)
     if "nords" in ABLATE:
         return []
     w = wreg(p)
+    if WRL:
+        return [f"ds_read_b128 v[{x0}:{x0 + 3}], v44", f"ds_read_b128 v[{x1}:{x1 + 3}], v45"] + wreadlanes(p)
     return [f"ds_read_b128 v[{x0}:{x0 + 3}], v44",
             f"ds_read_b128 v[{x1}:{x1 + 3}], v45",
             f"ds_read_b64 v[{w}:{w + 1}], %[wb] offset:{8 * p}"]
@@ -70,11 +93,20 @@ def reads(p):
 
 def fmas(p):
     s = sset(p)
-    x0, x1 = XREG[p % 2]
+    x0, x1 = xreg(p)
     if "nofma" in ABLATE:
         return []
     w = f"v[{wreg(p)}:{wreg(p) + 1}]"
     lo, hi = "op_sel_hi:[0,1,1]", "op_sel:[1,0,0] op_sel_hi:[1,1,1]"
+    if WRL:
+        w0, w1 = wsgpr(p)
+        return [f"s_set_gpr_idx_on s{s['pk0']}, gpr_idx(SRC2,DST)",
+                f"v_pk_fma_f32 v[64:65], s[{w0}:{w0 + 1}], v[{x0}:{x0 + 1}], v[64:65] {lo}",
+                f"v_pk_fma_f32 v[66:67], s[{w0}:{w0 + 1}], v[{x0 + 2}:{x0 + 3}], v[66:67] {lo}",
+                f"s_set_gpr_idx_idx s{s['pk1']}",
+                f"v_pk_fma_f32 v[64:65], s[{w1}:{w1 + 1}], v[{x1}:{x1 + 1}], v[64:65] {lo}",
+                f"v_pk_fma_f32 v[66:67], s[{w1}:{w1 + 1}], v[{x1 + 2}:{x1 + 3}], v[66:67] {lo}",
+                "s_set_gpr_idx_off"]
     return [f"s_set_gpr_idx_on s{s['pk0']}, gpr_idx(SRC2,DST)",
             f"v_pk_fma_f32 v[64:65], {w}, v[{x0}:{x0 + 1}], v[64:65] {lo}",
             f"v_pk_fma_f32 v[66:67], {w}, v[{x0 + 2}:{x0 + 3}], v[66:67] {lo}",
@@ -85,40 +117,41 @@ def fmas(p):
 
 
 def step(p):
-    """Steady-state step p: fetch pair p+1, prepare pair p+2, accumulate pair p."""
+    """Steady-state step p: fetch pair p+DEPTH, prepare pair p+DEPTH+1, accumulate pair p."""
     out = [f".Lw4_step{p}_%=:"]
-    if p + 1 < N_PAIRS:
-        out += reads(p + 1)
-    if p + 2 < N_PAIRS:
-        out += readlanes(p + 2)
-    if "nords" in ABLATE:
-        pass
-    else:
-        out.append("s_waitcnt lgkmcnt(3)" if p + 1 < N_PAIRS else "s_waitcnt lgkmcnt(0)")
+    if p + DEPTH < N_PAIRS:
+        out += reads(p + DEPTH)
+    if p + DEPTH + 1 < N_PAIRS:
+        out += readlanes(p + DEPTH + 1)
+    if "nords" not in ABLATE:
+        ahead = min(DEPTH, N_PAIRS - 1 - p)           # pairs fetched after pair p
+        out.append(f"s_waitcnt lgkmcnt({(2 if WRL else 3) * ahead})")
     out += fmas(p)
-    if p + 2 < N_PAIRS:
-        out += addresses(p + 2)
+    if p + DEPTH + 1 < N_PAIRS:
+        out += addresses(p + DEPTH + 1)
     if "xrl" in ABLATE:
-        out += ["v_readlane_b32 s92, %[pk], 3", "v_readlane_b32 s92, %[pk], 5"]
+        out += ["v_readlane_b32 s86, %[pk], 3", "v_readlane_b32 s86, %[pk], 5"]
     if "xvmov" in ABLATE:
         out += ["v_mov_b32 v39, v39", "v_mov_b32 v39, v39"]
     if "xsalu" in ABLATE:
-        out += ["s_mov_b32 s92, s92", "s_mov_b32 s92, s92"]
+        out += ["s_mov_b32 s86, s86", "s_mov_b32 s86, s86"]
     if "xlds" in ABLATE:
         out += ["ds_read_b32 v39, %[wb]"]
     return out
 
 
 def pre(p0):
-    """Warm-up for a chunk whose first pair is p0: what steps p0-2 and p0-1 would do, minus their FMAs."""
+    """Warm-up for a chunk whose first pair is p0: what the DEPTH+1 steps before step p0 would do, minus their FMAs."""
     out = [f".Lw4_pre{p0}_%=:"]
-    out += readlanes(p0)
-    if p0 + 1 < N_PAIRS:
-        out += readlanes(p0 + 1)
-    out += addresses(p0)
-    out += reads(p0)
-    if p0 + 1 < N_PAIRS:
-        out += addresses(p0 + 1)
+    for k in range(DEPTH + 1):
+        if p0 + k < N_PAIRS:
+            out += readlanes(p0 + k)
+    for k in range(DEPTH):
+        if p0 + k < N_PAIRS:
+            out += addresses(p0 + k)
+            out += reads(p0 + k)
+    if p0 + DEPTH < N_PAIRS:
+        out += addresses(p0 + DEPTH)
     out.append(f"s_branch .Lw4_step{p0}_%=")
     return out
 
@@ -128,10 +161,10 @@ def main(path):
     # computed branch: table of s_branch (4 bytes each), indexed by 32 - m
     lines += ["s_getpc_b64 s[94:95]",
               ".Lw4_pc_%=:",
-              "s_sub_u32 s92, 32, %[m]",
-              "s_lshl_b32 s92, s92, 2",
-              "s_add_u32 s92, s92, .Lw4_table_%= - .Lw4_pc_%=",
-              "s_add_u32 s94, s94, s92",
+              f"s_sub_u32 s{SCR}, 32, %[m]",
+              f"s_lshl_b32 s{SCR}, s{SCR}, 2",
+              f"s_add_u32 s{SCR}, s{SCR}, .Lw4_table_%= - .Lw4_pc_%=",
+              f"s_add_u32 s94, s94, s{SCR}",
               "s_addc_u32 s95, s95, 0",
               "s_setpc_b64 s[94:95]",
               ".Lw4_table_%=:"]

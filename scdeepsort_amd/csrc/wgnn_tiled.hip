@@ -402,7 +402,8 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
                      ::[pk] "v"(pk), [wa] "v"(wlane_addr), [wv] "v"(wv), [wb] "v"(wstrip_addr), [lb] "v"(lane16),
                        [mk] "v"(row_mask), [m] "s"(m)
                      : "m0", "memory", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v48", "v63", "v64", "v127",
-                       "s80", "s81", "s82", "s83", "s84", "s85", "s92", "s94", "s95");
+                       "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93",
+                       "s94", "s95");
     };
     // one source block.  CUR / NXT = register sets of blocks b / b+2; (cs, ce0) = this block's segment; (ns, ne) receive
     // the segment of block b+2 (kept in SGPRs until that block is consumed).
@@ -418,7 +419,7 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
         if (b + 1 < nblk && do_fill) fill(b + 1);
         if (b + 2 < nblk) chunk_load<NXT>(chunk_addr(ns, ne));
         const int buf_addr = (int)(size_t)smem + (b & 1) * buf_bytes;         // 1 KiB-aligned: smem is the only LDS object
-        if (do_comp && cs < ce0) {
+        if (do_comp && cs < ce0 && !((a.flags & (1u << 22)) && wave >= 8)) {   // bit 22 (timing experiment): half the waves idle
             consume(chunk_get<CUR>(), min(64, ce0 - cs), buf_addr);
             for (int s = cs + 64; s < ce0; s += 64) {        // rare: more than 64 entries for this wave in one block
                 chunk_load<CUR>(chunk_addr(s, ce0));        // (E(b+2) is in flight behind it: wait for both)

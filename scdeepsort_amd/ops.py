@@ -240,7 +240,7 @@ def agg_fwd_tiled(csr: AggCsr, tplan, alpha: Optional[torch.Tensor], mode: int, 
     if ev is not None:
         ev[1].record(torch.cuda.current_stream(dev))
         PROFILE.append((("rows", csr.n_rows, "cols", csr.n_cols, "nnz", csr.nnz, "D", D, "mode", mode,
-                         "kernel", "agg_tiled_flat" if D == 256 else "agg_tiled"), ev[0], ev[1]))
+                         "kernel", "agg_tiled_flat4" if D == 256 else "agg_tiled"), ev[0], ev[1]))
     return out
 
 

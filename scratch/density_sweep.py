@@ -1,0 +1,23 @@
+import sys, time, torch
+sys.path.insert(0, '/root/repo')
+import scdeepsort_amd as sda
+from scdeepsort_amd import synthetic as S, ops
+dev='cuda:0'
+G,C,H=20000,100000,256
+def timeit(f,n=20):
+    f(); torch.cuda.synchronize(); t=time.perf_counter()
+    for _ in range(n): f()
+    torch.cuda.synchronize(); return (time.perf_counter()-t)/n*1e3
+B=lambda *bits: sum(1<<b for b in bits)
+hg=S.synth_features(G,H,device=dev); hc=S.synth_features(C,H,seed=3,device=dev)
+alpha=torch.rand(G+2,device=dev)+0.5
+for dens in (0.005,0.01,0.02,0.04,0.08):
+    rp,col,val=S.synth_expression(C,G,density=dens,device=dev)
+    g=sda.CellGeneGraph.from_device_csr(rp,col,val,G)
+    tpc=g.cg.tile_plan(78)
+    out=[]
+    for nm,fl in [('full',0),('nofill',B(16)),('nofill+nobar',B(16,18)),('nocompute',B(17))]:
+        ops.DEBUG_FLAGS=fl
+        out.append(f"{nm} {timeit(lambda: ops.agg_fwd_tiled(g.cg,tpc,alpha,sda.SRC_IS_GENE,G+1,hg,hc)):.3f}")
+    print(f"density {dens} nnz {g.cg.nnz/1e6:.1f}M tiles {tpc.items.shape[0]} | "+' | '.join(out), flush=True)
+    del g,tpc,rp,col,val

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
-timeout 600 rocprofv3 --kernel-trace --pmc $@ --output-format csv -d $OUT -o p -- python scratch/one_kernel.py > $OUT/log.txt 2>&1
+timeout 600 rocprofv3 --kernel-trace --pmc $@ --output-format csv -d $OUT -o p -- env WGNN_ONE_PASS=1 python scratch/one_kernel.py > $OUT/log.txt 2>&1
 F=$(find $OUT -name "*counter_collection.csv" | head -1)
 python - "$F" <<'PY'
 import csv, sys, collections

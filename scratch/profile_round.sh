@@ -11,10 +11,6 @@ rm -rf $OUT; mkdir -p $OUT
 cd $ROOT
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o fwd -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench.log 2>&1
 grep '^{' $OUT/bench.log | tail -1 > $OUT/bench_line.json
-sed -i 's/,flat=True//g' scratch/one_kernel.py
-python - <<'PY' >> scratch/one_kernel.py
-print("ops.agg_fwd_tiled(g.gc,tpg,alpha,sda.DST_IS_GENE,G,hc,hg); torch.cuda.synchronize()")
-PY
 for C in FETCH_SIZE WRITE_SIZE "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_HIT_sum TCC_MISS_sum"; do
   T=$(echo $C | tr ' ' '_')
   timeout 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $OUT/pmc_$T -o p -- python scratch/one_kernel.py > $OUT/pmc_$T.log 2>&1
