@@ -176,162 +176,21 @@ __global__ void __launch_bounds__(kTW * 64) agg_tiled(const KArgs a, const TArgs
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// D == 256 specialisation: FLAT entry loop with a hand-scheduled pipeline.
-//  * Register file split: the compiler may allocate v[0:47] only (amdgpu_num_vgpr(48)); v[48:63] are two
-//    LDS staging buffers (XA, XB: two float4 each) and v[64:127] the wave's 16 x float4 accumulators.
-//    Those 80 registers are touched exclusively by literal-register inline asm, so the compiler never
-//    copies or spills them.
-//  * The destination row of an entry is a run-time value: the accumulators are addressed through GPR-index
-//    mode (s_set_gpr_idx_on: VGPR number += M0[7:0]), so there is no per-row control flow - an entry costs
-//    2 v_readlane + 1 v_add + 1 ds_read_b128 + 2 v_pk_fma_f32.
-//  * Entries are consumed in pairs through a two-stage pipeline: pair g+1's LDS reads are in flight while pair
-//    g's FMAs issue; every wait is a static count.
-// ---------------------------------------------------------------------------------------------
-struct Sc2 { int r0, r1; unsigned long long w0, w1; };     // per-entry scalars: pk (low byte = 4*slot), weight
-struct Ad2 { int a0, a1; };                                // per-lane LDS byte addresses of a pair
-
-#define WGNN_FMA2_TXT(X0, X1, X2, X3)                                                             \
-    "s_set_gpr_idx_on %[r0], gpr_idx(SRC2,DST)\n\t"                                              \
-    "v_pk_fma_f32 v[64:65], %[w0], v[" #X0 "], v[64:65] op_sel_hi:[0,1,1]\n\t"                    \
-    "v_pk_fma_f32 v[66:67], %[w0], v[" #X1 "], v[66:67] op_sel_hi:[0,1,1]\n\t"                    \
-    "s_set_gpr_idx_idx %[r1]\n\t"                                                                 \
-    "v_pk_fma_f32 v[64:65], %[w1], v[" #X2 "], v[64:65] op_sel_hi:[0,1,1]\n\t"                    \
-    "v_pk_fma_f32 v[66:67], %[w1], v[" #X3 "], v[66:67] op_sel_hi:[0,1,1]\n\t"                    \
-    "s_set_gpr_idx_off"
-#define WGNN_FMA2_A WGNN_FMA2_TXT(48:49, 50:51, 52:53, 54:55)
-#define WGNN_FMA2_B WGNN_FMA2_TXT(56:57, 58:59, 60:61, 62:63)
-#define WGNN_SC_IN(S_) [r0] "s"(S_.r0), [r1] "s"(S_.r1), [w0] "s"(S_.w0), [w1] "s"(S_.w1)
-#define WGNN_AD_IN(A_) [a0] "v"(A_.a0), [a1] "v"(A_.a1)
 #define WGNN_CLOB "m0", "memory", "v48", "v63", "v64", "v127"
 
-#define WGNN_PRIME_A(AD_)                                                                         \
-    asm volatile("ds_read_b128 v[48:51], %[a0]\n\tds_read_b128 v[52:55], %[a1]" ::WGNN_AD_IN(AD_) : WGNN_CLOB)
-#define WGNN_STEP_AB(SC_, AD_)     /* current = XA, next pair's reads -> XB */                    \
-    asm volatile("ds_read_b128 v[56:59], %[a0]\n\tds_read_b128 v[60:63], %[a1]\n\t"               \
-                 "s_waitcnt lgkmcnt(2)\n\t" WGNN_FMA2_A ::WGNN_SC_IN(SC_), WGNN_AD_IN(AD_) : WGNN_CLOB)
-#define WGNN_STEP_BA(SC_, AD_)     /* current = XB, next pair's reads -> XA */                    \
-    asm volatile("ds_read_b128 v[48:51], %[a0]\n\tds_read_b128 v[52:55], %[a1]\n\t"               \
-                 "s_waitcnt lgkmcnt(2)\n\t" WGNN_FMA2_B ::WGNN_SC_IN(SC_), WGNN_AD_IN(AD_) : WGNN_CLOB)
-#define WGNN_LAST_A(SC_) asm volatile("s_waitcnt lgkmcnt(0)\n\t" WGNN_FMA2_A ::WGNN_SC_IN(SC_) : WGNN_CLOB)
-#define WGNN_DRAIN() asm volatile("s_waitcnt lgkmcnt(0)" ::: WGNN_CLOB)
-
-template <typename TOut, int EPI>
-__global__ void __launch_bounds__(kTW * 64) __attribute__((amdgpu_num_vgpr(48)))
-agg_tiled_flat(const KArgs a, const TArgs t) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int row_bytes = 1024;
-    const int kKB = t.kb, buf_bytes = kKB * row_bytes;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int tile = blockIdx.x;
-    const int2 hdr = t.tile_hdr[tile];
-    const int cb = __builtin_amdgcn_readfirstlane(hdr.x), ce = __builtin_amdgcn_readfirstlane(hdr.y);
-    const int nblk = (ce - cb + kKB - 1) / kKB;
-    cptr_t seg = (cptr_t)(t.seg_ptr + ((size_t)tile * t.nblk_max) * kTW + wave);
-    const bool do_fill = !(a.flags & kDbgNoFill), do_comp = !(a.flags & kDbgNoCompute);
-
-    for (int r = 0; r < kRPW; ++r)                       // zero the accumulators v[64:127]
-        asm volatile("s_set_gpr_idx_on %0, gpr_idx(DST)\n\tv_mov_b32 v64, 0\n\tv_mov_b32 v65, 0\n\t"
-                     "v_mov_b32 v66, 0\n\tv_mov_b32 v67, 0\n\ts_set_gpr_idx_off" ::"s"(r * 4) : WGNN_CLOB);
-
-    auto fill = [&](int b, int buf) {
-        const int r0 = cb + b * kKB;
-        const int nbytes = min(kKB, ce - r0) * row_bytes;
-        const char* g = reinterpret_cast<const char*>(a.src) + (size_t)r0 * row_bytes;
-        char* l = smem + buf * buf_bytes;
-        for (int p = wave; p * 1024 < nbytes; p += kTW)
-            __builtin_amdgcn_global_load_lds((gptr_t)(g + p * 1024 + lane * 16), (lptr_t)(l + p * 1024), 16, 0, 0);
-    };
-    // lane j <- entry s+j; lanes past the segment end replicate its LAST entry (consume() zeroes their weight), so a
-    // chunk can always be processed in whole pairs: the padding adds 0 * x of a source row the destination already
-    // uses.  Nothing here touches the loaded value, so the load stays in flight until the next block.
-    auto load_chunk = [&](int s, int e, int2& ent) {
-        ent = make_int2(0, 0);
-        if (s < e) ent = t.entries[min(s + lane, e - 1)];
-    };
-    // n (<= 64) entries of one chunk; meta = dst_slot<<8 | src_local
-    auto consume = [&](const int2& ent, int n, const char* lbuf) {
-        const int pk = ((ent.x & 0xFF) << 18) | ((ent.x >> 8) << 2);       // (src_local*1024)<<8 | 4*slot
-        const int wv = lane < n ? ent.y : 0;                               // padding lanes: weight 0
-        const int lbase = (int)(size_t)lbuf;                               // LDS byte address of this lane's slice
-        auto scal = [&](int j, Sc2& c, Ad2& ad) {
-            c.r0 = __builtin_amdgcn_readlane(pk, j); c.r1 = __builtin_amdgcn_readlane(pk, j + 1);
-            c.w0 = (unsigned)__builtin_amdgcn_readlane(wv, j); c.w1 = (unsigned)__builtin_amdgcn_readlane(wv, j + 1);
-            ad.a0 = lbase + (int)((unsigned)c.r0 >> 8); ad.a1 = lbase + (int)((unsigned)c.r1 >> 8);
-        };
-        const int ng = (n + 1) >> 1;                      // padded to whole pairs: see load_chunk
-        if (ng > 0) {
-            Sc2 cA, cB; Ad2 dA, dB;
-            scal(0, cA, dA);
-            WGNN_PRIME_A(dA);
-            int g = 0;
-            for (; g + 2 <= ng; g += 2) {                 // invariant: XA holds (in flight) pair g, cA its scalars
-                scal(2 * g + 2, cB, dB);
-                WGNN_STEP_AB(cA, dB);
-                scal(2 * g + 4, cA, dA);                  // may run past n (padding lanes): harmless reads
-                WGNN_STEP_BA(cB, dA);
-            }
-            if (g < ng) { WGNN_LAST_A(cA); } else { WGNN_DRAIN(); }         // retire the look-ahead reads
-        }
-    };
-    auto block = [&](int b, int& cs, int& ce0, const int2& cur0, int ns, int ne, int2& nxt0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // my DMA pieces of block b and my entry chunk have landed
-        if (!(a.flags & kDbgNoBarrier)) __syncthreads();      // everyone's have; everyone is done with block b-1
-        asm volatile("" ::"s"(ns), "s"(ne));                  // retire the scalar loads issued at the end of block b-1
-        if (b + 1 < nblk) {
-            load_chunk(ns, ne, nxt0);
-            if (do_fill) fill(b + 1, (b + 1) & 1);
-        }
-        const int cs_ = cs, ce_ = ce0;
-        const char* lbuf = smem + (b & 1) * buf_bytes + lane * 16;
-        int q = 0;
-        for (int s = cs_; s < ce_ && do_comp; s += 64, ++q) {
-            int2 ent = cur0;
-            if (q >= 1) load_chunk(s, ce_, ent);              // rare: more than 64 entries for this wave in one block
-            consume(ent, min(64, ce_ - s), lbuf);
-        }
-        asm volatile("" ::: "memory");
-        if (b + 2 < nblk) { cs = seg[(b + 2) * kTW]; ce0 = seg[(b + 2) * kTW + 1]; }
-    };
-
-    if (nblk > 0) {
-        int sA = seg[0], eA = seg[1], sB = 0, eB = 0;
-        if (nblk > 1) { sB = seg[kTW]; eB = seg[kTW + 1]; }
-        int2 a0, b0;
-        load_chunk(sA, eA, a0);
-        b0 = make_int2(0, 0);
-        if (do_fill) fill(0, 0);
-        for (int b = 0; b < nblk; b += 2) {
-            block(b, sA, eA, a0, sB, eB, b0);
-            if (b + 1 < nblk) block(b + 1, sB, eB, b0, sA, eA, a0);
-        }
-    }
-
-    const int4* __restrict__ items = t.tile_items + (size_t)tile * kTileRows + wave * kRPW;
-    for (int i = 0; i < kRPW; ++i) {
-        const int4 it = items[i];
-        const int slot = __builtin_amdgcn_readfirstlane(it.x), pslot = __builtin_amdgcn_readfirstlane(it.w);
-        if (slot < 0) continue;
-        float4 v;
-        asm volatile("s_set_gpr_idx_on %4, gpr_idx(SRC0)\n\tv_mov_b32 %0, v64\n\tv_mov_b32 %1, v65\n\t"
-                     "v_mov_b32 %2, v66\n\tv_mov_b32 %3, v67\n\ts_set_gpr_idx_off"
-                     : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w) : "s"(i * 4) : "m0");
-        if (pslot >= 0) {
-            st4(a.partials + (size_t)pslot * a.D + lane * 4, v);
-        } else {
-            float4 one[1] = {v};
-            epilogue<64, 1, float, TOut, EPI>(a, one, slot, lane, true);
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------
-// agg_tiled_flat4: same tile / block structure, but (a) the per-entry loop is the generated straight-line pipeline of
-// gen_flat_asm.py and (b) EVERY vector-memory operation of the block loop - entry-chunk loads, segment loads, the
-// global->LDS DMA - is issued from inline asm into literal registers, with hand-counted s_waitcnt.  The compiler
-// otherwise protects each VGPR load result / LDS access with `s_waitcnt vmcnt(0)` placed AFTER the next block's DMA
-// has been issued, which serialises fill and compute.
+// agg_tiled_flat4 - the D == 256 specialisation.  Same tile / block structure as agg_tiled, but
+//  * the register file is split: the compiler may allocate v[0:31] / s[0:79] only (amdgpu_num_vgpr / amdgpu_num_sgpr);
+//    v[64:127] are the wave's 16 x float4 accumulators, v[48:63] two LDS staging buffers, v[32:45] chunk / segment /
+//    weight / address registers, s[80:95] per-entry scalars.  They are touched exclusively by literal-register inline
+//    asm, so the compiler never copies or spills them;
+//  * the destination row of an entry is a run-time value: the accumulators are addressed through GPR-index mode
+//    (s_set_gpr_idx_on: VGPR number += M0[7:0]), so there is no per-row control flow;
+//  * the per-entry loop is the generated straight-line pipeline of gen_flat_asm.py (4 VALU per entry);
+//  * EVERY vector-memory operation of the block loop - entry-chunk loads, segment loads, the global->LDS DMA - is
+//    issued from inline asm into literal registers, with hand-counted s_waitcnt.  The compiler otherwise protects
+//    each VGPR load result / LDS access with `s_waitcnt vmcnt(0)` placed AFTER the next block's DMA has been issued,
+//    which serialises fill and compute.
 //   v[32:33] segment {begin, end} of block b+3 ; v[34:35], v[36:37], v[38:39] entry chunks of blocks b, b+1, b+2 (mod 3)
 // VMEM issue order inside block b:  S(b+3), DMA pieces of block b+1, E(b+2)   =>  at the top of block b+1 everything
 // but E(b+2) must have landed: s_waitcnt vmcnt(1).  An entry chunk therefore has two block times to arrive.
@@ -477,19 +336,12 @@ int launch_tiled(const KArgs& a, const TArgs& t, long n_tiles, hipStream_t st) {
     if (a.D == 256 && !(a.flags & (1u << 19))) {       // bit 19: force the generic (row-visit) kernel, for A/B timing
         static int flat_configured = 0;
         if (flat_configured < lds) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_tiled_flat<TOut, EPI>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-                return WGNN_ERR_LAUNCH;
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_tiled_flat4<TOut, EPI>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
                 return WGNN_ERR_LAUNCH;
             flat_configured = lds;
         }
-        if (a.flags & (1u << 20)) {                    // bit 20: previous (compiler-scheduled loop) flat kernel, for A/B timing
-            hipLaunchKernelGGL((agg_tiled_flat<TOut, EPI>), dim3((unsigned)n_tiles), dim3(kTW * 64), lds, st, a, t);
-        } else {
-            hipLaunchKernelGGL((agg_tiled_flat4<TOut, EPI>), dim3((unsigned)n_tiles), dim3(kTW * 64), lds, st, a, t);
-        }
+        hipLaunchKernelGGL((agg_tiled_flat4<TOut, EPI>), dim3((unsigned)n_tiles), dim3(kTW * 64), lds, st, a, t);
     } else {
         hipLaunchKernelGGL((agg_tiled<TOut, EPI>), dim3((unsigned)n_tiles), dim3(kTW * 64), lds, st, a, t);
     }
