@@ -21,7 +21,7 @@ gloo; the product binds it to the HIP operators.
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Callable, Optional, Tuple
+from typing import Callable, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -100,14 +100,17 @@ class LocalOps:
 
 
 def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local: torch.Tensor, ops: LocalOps,
-                    n_layers: int, gather_logits: bool = True) -> torch.Tensor:
-    """Layer-wise forward over a cell shard.  ``weights`` = list of (W_i, b_i) + (W_out, b_out) last."""
+                    n_layers: int, gather_logits: bool = True, shard_sizes: Optional[Sequence[int]] = None) -> torch.Tensor:
+    """Layer-wise forward over a cell shard.  ``weights`` = list of (W_i, b_i) + (W_out, b_out) last.
+    Features may be stored in fp16 (BASELINE cfg5): they are widened on the way into the fp32 projection, i.e. the
+    arithmetic is "fp16-rounded inputs, fp32 accumulate".  ``shard_sizes`` (cells per rank, known at graph build)
+    lets the logits concat run without a size exchange / host sync."""
     h_g, h_c = feats_g, feats_c_local
     for i in range(n_layers):
         W, b = weights[i]
         last = i == n_layers - 1
-        p_g = torch.nn.functional.linear(h_g, W)
-        p_c = torch.nn.functional.linear(h_c, W)
+        p_g = torch.nn.functional.linear(h_g.to(W.dtype), W)
+        p_c = torch.nn.functional.linear(h_c.to(W.dtype), W)
         new_c = ops.cells_layer(p_g, p_c, b, True)
         if not last:
             part = ops.genes_partial(p_c)
@@ -120,7 +123,18 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
     Wo, bo = weights[n_layers]
     logits = torch.nn.functional.linear(h_c, Wo, bo)
     rank, ws = world()
+    if gather_logits and ws > 1 and shard_sizes is not None and len(set(shard_sizes)) == 1:
+        out = torch.empty((ws * logits.shape[0], logits.shape[1]), dtype=logits.dtype, device=logits.device)
+        dist.all_gather_into_tensor(out, logits.contiguous())           # X3: inference concat, equal shards
+        return out
     if gather_logits and ws > 1:
+        if shard_sizes is not None:
+            mx = max(shard_sizes)
+            pad = torch.zeros(mx, logits.shape[1], dtype=logits.dtype, device=logits.device)
+            pad[: logits.shape[0]] = logits
+            outs = [torch.empty_like(pad) for _ in range(ws)]
+            dist.all_gather(outs, pad)
+            return torch.cat([o[:n] for o, n in zip(outs, shard_sizes)])
         sizes = [torch.zeros(1, dtype=torch.long, device=logits.device) for _ in range(ws)]
         dist.all_gather(sizes, torch.tensor([logits.shape[0]], dtype=torch.long, device=logits.device))
         mx = int(max(s.item() for s in sizes))

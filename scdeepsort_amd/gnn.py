@@ -74,6 +74,8 @@ class GNN(nn.Module):
         project_first = self.order == "project_first" or (self.order == "auto" and W.shape[0] <= W.shape[1])
         if self.dropout is not None:                       # node rows, before the gather (gnn.py:62-64)
             h_g, h_c = self.dropout(h_g), self.dropout(h_c)
+        if h_g.dtype != W.dtype:                           # fp16-stored features (BASELINE cfg5): widened on the way
+            h_g, h_c = h_g.to(W.dtype), h_c.to(W.dtype)     # into the fp32 projection (fp16-rounded inputs, fp32 accumulate)
 
         def finish(x):
             if act is not None and not fuse_relu:

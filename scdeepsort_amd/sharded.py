@@ -17,8 +17,9 @@ from .ops import agg_fwd, weighted_mean_aggregate, weighted_sum
 
 
 class ShardedWgnn:
-    def __init__(self, model: GNN, graph: CellGeneGraph, world: int):
+    def __init__(self, model: GNN, graph: CellGeneGraph, world: int, shard_sizes=None):
         self.model, self.graph, self.world = model, graph, world
+        self.shard_sizes = shard_sizes          # cells per rank (exchanged once at build): sync-free logits concat
 
     @property
     def nnz(self) -> int:
@@ -54,7 +55,14 @@ class ShardedWgnn:
             gc._t = None
             gc._tile_plan = None
             world = max(world, 2)
-        return ShardedWgnn(model, g, world)
+        sizes = None
+        if D.world()[1] > 1:
+            import torch.distributed as tdist
+            mine = torch.tensor([g.num_cells], dtype=torch.long, device=col.device)
+            every = [torch.zeros_like(mine) for _ in range(D.world()[1])]
+            tdist.all_gather(every, mine)
+            sizes = [int(t.item()) for t in every]
+        return ShardedWgnn(model, g, world, sizes)
 
     # -- local arithmetic bound to the HIP kernels (differentiable: K1 forward, K2/K3 backward) ---------
     def _ops(self) -> D.LocalOps:
@@ -90,20 +98,22 @@ class ShardedWgnn:
         m = self.model
         if self.world == 1:
             return m.linear(m.embed(self.graph, (feats_g, feats_c_local)))
-        return D.sharded_forward(self._weights(), None, feats_g, feats_c_local, self._ops(), m.n_layers, gather_logits)
+        return D.sharded_forward(self._weights(), None, feats_g, feats_c_local, self._ops(), m.n_layers, gather_logits,
+                                 self.shard_sizes)
 
-    def forward_alg_bytes(self, dense_dim: int, s: int = 4) -> int:
-        """Algorithmic HBM bytes of one 2-layer forward on this rank (SURVEY.md section 8d formula)."""
+    def forward_alg_bytes(self, dense_dim: int, s0: int = 4) -> int:
+        """Algorithmic HBM bytes of one 2-layer forward on this rank (SURVEY.md section 8d formula); ``s0`` = bytes per
+        element of the layer-0 features (2 for fp16 storage), deeper layers are fp32."""
         g, m = self.graph, self.model
         G, C = g.num_genes, g.num_cells
         H = m.layers[0].fc_neigh.weight.shape[0]
-        def b(nnz, R, S, din, dout):
-            return 8 * nnz + 4 * (R + 1) + s * din * (S + R) + 4 * G + s * dout * R
-        tot, din = 0, dense_dim
+        def b(nnz, R, S, din, dout, s):
+            return 8 * nnz + 4 * (R + 1) + s * din * (S + R) + 4 * G + 4 * dout * R
+        tot, din, s = 0, dense_dim, s0
         for i in range(m.n_layers):
             last = i == m.n_layers - 1
             if not last:
-                tot += b(g.gc.nnz, G, C, din, H)
-            tot += b(g.cg.nnz, C, G, din, H)
-            din = H
+                tot += b(g.gc.nnz, G, C, din, H, s)
+            tot += b(g.cg.nnz, C, G, din, H, s)
+            din, s = H, 4
         return tot

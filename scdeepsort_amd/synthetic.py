@@ -29,13 +29,15 @@ class Config:
     n_classes: int = 16
     n_layers: int = 2
     density: float = 0.04
+    feature_dtype: torch.dtype = torch.float32     # storage type of the node features (cfg5: fp16)
+    total_cells: bool = False                      # True: `cells` is the WHOLE job, sharded over the ranks (strong scaling)
 
 
 CONFIGS = {
     "tiny": Config("tiny", 512, 256, 32, dense_dim=40),
     "cfg2": Config("cfg2", 10_000, 5_000, 128),
     "cfg3": Config("cfg3", 100_000, 20_000, 256),
-    "cfg5": Config("cfg5", 764_741, 20_000, 256),
+    "cfg5": Config("cfg5", 764_741, 20_000, 256, feature_dtype=torch.float16, total_cells=True),
 }
 
 

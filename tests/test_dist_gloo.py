@@ -23,7 +23,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, cells=90):
     import scipy.sparse as sp
     from conftest import small_case
     from oracle import wgnn_oracle as O
@@ -31,7 +31,7 @@ def _worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        c = small_case(cells=90, genes=40, dim=12, hidden=8, n_classes=3, seed=21, test_cells=0)
+        c = small_case(cells=cells, genes=40, dim=12, hidden=8, n_classes=3, seed=21, test_cells=0)
         G, C = c["G"], c["C"]
         sd = O.init_params(12, 8, 3, 2, G, seed=3, dtype=torch.float64)
         expr = sp.csr_matrix(c["expr"]).astype(np.float64)
@@ -70,6 +70,15 @@ def _worker(rank, world, port, out_dir):
         logits = D.sharded_forward(weights, None, feats[:G], feats[G + lo:G + hi], ops, 2, gather_logits=True)
         full = O.csr_forward(sd, ref, c["feats"].astype(np.float64), 2, dtype=np.float64)
         np.testing.assert_allclose(logits.numpy(), full, atol=1e-6)          # every rank holds ALL cells' logits, in order
+        # shard sizes known at graph build: the concat needs no size exchange (equal shards -> one all_gather_into_tensor)
+        sizes = [D.shard_range(C, r, world)[1] - D.shard_range(C, r, world)[0] for r in range(world)]
+        l2 = D.sharded_forward(weights, None, feats[:G], feats[G + lo:G + hi], ops, 2, True, sizes)
+        assert torch.equal(l2, logits)
+        # fp16-stored features (cfg5): widened on the way into the projection
+        f16 = feats.half()
+        l3 = D.sharded_forward(weights, None, f16[:G], f16[G + lo:G + hi], ops, 2, True, sizes)
+        l3ref = D.sharded_forward(weights, None, f16[:G].double(), f16[G + lo:G + hi].double(), ops, 2, True, sizes)
+        assert torch.equal(l3, l3ref)
 
         # ---- data-parallel training step (cfg4): grads after SUM all-reduce == single-process autograd grads
         labels = torch.from_numpy(np.random.default_rng(5).integers(0, 3, C))
@@ -100,9 +109,10 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_world2_sharded_forward_matches_unsharded(tmp_path):
+@pytest.mark.parametrize("cells", [90, 91])           # equal shards (one all_gather_into_tensor) / ragged shards
+def test_world2_sharded_forward_matches_unsharded(tmp_path, cells):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), cells), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
 
 

@@ -466,3 +466,19 @@ def test_sampled_nodeflow_properties():
     np.testing.assert_allclose(big.cpu().numpy(), full.cpu().numpy(), atol=TOL)
     assert torch.equal(a, b)                      # same seed, same draw
     assert not torch.equal(a, d)
+
+
+def test_fp16_stored_features_match_oracle_on_rounded_inputs():
+    """BASELINE cfg5: node features stored in fp16; the restatement gets the same fp16-rounded values and accumulates
+    in fp32 (SURVEY 8d tolerance row)."""
+    c = small_case(seed=41)
+    sd = O.init_params(c["dim"], c["hidden"], c["n_classes"], 2, c["G"], seed=11)
+    cg = O.build_csr_graph(c["expr"], c["support_mask"])
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
+    f16 = dev(c["feats"]).half()
+    want = O.csr_forward(sd, cg, f16.float().cpu().numpy(), 2)
+    for order in ("project_first", "aggregate_first"):
+        m = make_model(sd, c["dim"], c["hidden"], c["n_classes"], 2, c["G"], order)
+        with torch.no_grad():
+            got = m(g, f16).cpu().numpy()
+        np.testing.assert_allclose(got, want, atol=TOL, err_msg=order)
