@@ -65,10 +65,25 @@ class GNN(nn.Module):
         self.order = "auto"          # "auto" | "project_first" | "aggregate_first"
 
     # -- one NodeFlow block, both node types ------------------------------------------------------
+    def _pad_width(self, g: CellGeneGraph, H: int) -> int:
+        """Large graphs run the LDS-streamed kernel, whose hand-scheduled D = 256 specialisation is ~2x faster per
+        edge than the generic one: a hidden width in (192, 256) - e.g. the reference default hidden_dim = 200,
+        train.py:137 - is carried as 256 columns with zero weights / bias in the padding (exact: the extra columns stay 0
+        through ReLU and meet zero weight columns in the next layer)."""
+        from . import ops
+        if 192 < H < 256 and ops.TILED_MIN_WORK is not None and g.cg.nnz * 256 >= ops.TILED_MIN_WORK:
+            return 256
+        return H
+
     def _layer(self, g: CellGeneGraph, layer: NodeUpdate, h_g: torch.Tensor, h_c: torch.Tensor,
                want_genes: bool, cell_rows: Optional[torch.Tensor]):
         G = self.gene_num
         W, b = layer.fc_neigh.weight, layer.fc_neigh.bias
+        if h_g.shape[1] > W.shape[1]:                      # input carried padded (see _pad_width): zero weight columns
+            W = F.pad(W, (0, h_g.shape[1] - W.shape[1]))
+        Hp = self._pad_width(g, W.shape[0])
+        if Hp != W.shape[0] and layer.norm is None:
+            W, b = F.pad(W, (0, 0, 0, Hp - W.shape[0])), F.pad(b, (0, Hp - b.shape[0]))
         act = layer.activation
         fuse_relu = _is_relu(act)
         project_first = self.order == "project_first" or (self.order == "auto" and W.shape[0] <= W.shape[1])
@@ -127,7 +142,8 @@ class GNN(nn.Module):
         for i, layer in enumerate(self.layers):
             last = i == self.n_layers - 1
             h_g, h_c = self._layer(g, layer, h_g, h_c, want_genes=not last, cell_rows=cell_rows if last else None)
-        return h_c
+        H = self.layers[-1].fc_neigh.weight.shape[0]
+        return h_c if h_c.shape[1] == H else h_c[:, :H]
 
     def embed_sampled(self, g: CellGeneGraph, features, nodeflow) -> torch.Tensor:
         """Seed-cell embeddings over a drawn NodeFlow (``sampler.sample_nodeflow``): the ``num_neighbors > 0`` mode

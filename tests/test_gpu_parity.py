@@ -363,7 +363,7 @@ def test_sharded_train_step_world1_matches_plain_autograd():
     assert eng.world == 2
     opt = torch.optim.SGD(m.parameters(), lr=0.0)
     total = eng.train_step(feats[:G], feats[G:], labels, opt)
-    assert total == pytest.approx(float(loss_ref), rel=1e-5)
+    assert total == pytest.approx(float(loss_ref.detach()), rel=1e-5)
     for k, p in m.named_parameters():
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref[k].cpu().numpy(), atol=2e-4, rtol=1e-3, err_msg=k)
 
@@ -482,3 +482,38 @@ def test_fp16_stored_features_match_oracle_on_rounded_inputs():
         with torch.no_grad():
             got = m(g, f16).cpu().numpy()
         np.testing.assert_allclose(got, want, atol=TOL, err_msg=order)
+
+
+def test_hidden_200_is_carried_as_256_columns_on_the_tiled_path():
+    """Reference default hidden_dim = 200 (train.py:137): on graphs big enough for the LDS-streamed kernel the hidden
+    width is zero-padded to 256 so the D = 256 specialisation runs; logits and gradients are unchanged."""
+    from scdeepsort_amd import ops
+    c = small_case(cells=300, genes=180, dim=260, hidden=200, n_classes=6, seed=51, test_cells=0)
+    G = c["G"]
+    sd = O.init_params(260, 200, 6, 2, G, seed=12)
+    rg = O.build_reference_graph(c["expr"])
+    seeds = np.arange(G, G + c["C"])
+    labels = torch.from_numpy(np.random.default_rng(3).integers(0, 6, c["C"]))
+    loss_ref, grads_ref, logits_ref = O.loss_and_grads(sd, rg, torch.from_numpy(c["feats"]), seeds, labels, 2)
+    g = sda.CellGeneGraph.from_expression(c["expr"], device=DEV)
+    m = make_model(sd, 260, 200, 6, 2, G)
+    saved = ops.TILED_MIN_WORK
+    ops.TILED_MIN_WORK = 1
+    try:
+        assert m._pad_width(g, 200) == 256
+        ops.PROFILE = []
+        logits = m(g, dev(c["feats"]))
+        kernels = {dict(zip(t[::2], t[1::2]))["kernel"] for t, _, _ in ops.PROFILE}
+        ops.PROFILE = None
+        assert kernels == {"agg_tiled_flat4"}
+        loss = F.cross_entropy(logits, labels.to(DEV), reduction="sum")
+        loss.backward()
+    finally:
+        ops.TILED_MIN_WORK = saved
+        ops.PROFILE = None
+    assert logits.shape == (c["C"], 6)
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), logits_ref.detach().numpy(), atol=TOL)
+    for n, p in m.named_parameters():
+        ref = grads_ref[n].numpy()
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=TOL * max(1.0, float(np.abs(ref).max())), err_msg=n)
+    assert m.embed(g, dev(c["feats"])).shape[1] == 200
