@@ -70,6 +70,13 @@ extern "C" {
 int         wgnn_version(void);
 const char* wgnn_last_error_string(int code);
 
+/* Bytes of caller-provided scratch one aggregation call needs (the library never allocates):
+ *   *partials_bytes    = n_partials * D * 4                      (long-row / column-split partial sums)
+ *   *src_scratch_bytes = n_src * D * 4 for the tiled kernels that fold a per-row factor into the source table
+ *                        (wgnn_agg_fwd_tiled with WGNN_SRC_IS_GENE, wgnn_agg_bwd_src_tiled's g_scratch), else 0. */
+int wgnn_agg_workspace_bytes(int64_t n_partials, int64_t n_src, int32_t D, int alpha_mode, int tiled,
+                             int64_t* partials_bytes, int64_t* src_scratch_bytes);
+
 /* ---------------------------------------------------------------------------
  * Execution plan: splits long rows into fixed-size chunks so that a hub gene
  * with ~C in-edges does not serialise on one wavefront.  Built once per CSR
@@ -115,15 +122,16 @@ int wgnn_agg_fwd(const int32_t* rowptr, const int32_t* col, const float* val,
 /* ---------------------------------------------------------------------------
  * K1t forward, LDS-streamed variant of K1 (same arithmetic, same outputs) for D <= 256, f32,
  *     h_src contiguous (leading dimension == D).  One 1024-thread workgroup per TILE of up to 256
- *     destination rows (16 waves x 16 rows); the source table is streamed through LDS in 64-row
- *     blocks.  The tile plan is a re-ordering of the CSR (built once per graph):
+ *     destination rows (16 waves x 16 rows); the source table is streamed through LDS in blocks of
+ *     `block_rows` rows.  The tile plan is a re-ordering of the CSR (built once per graph):
  *
  *   tile_hdr   : int32[n_tiles * 2]        {col_begin, col_end} = source range the tile reduces over
  *   tile_items : int32[n_tiles * 256 * 4]  per tile, wave-major: {row_slot | -1 (padding), -, -, partial_slot | -1}
  *   entries    : int32[nnz * 2]            {dst_slot_in_wave << 8 | src_row_in_block, weight (f32 bits)}
  *                                          sorted by (tile, block, wave, dst_slot); block = (col-col_begin)/64
  *   seg_ptr    : int32[n_tiles*nblk_max*16 + 1]  entry offsets per (tile, block, wave)
- *   block_rows : source rows per LDS block the plan was built for (16..255; 2*block_rows*D*4 B <= 160 KiB)
+ *   block_rows : source rows per LDS block the plan was built for (16..255; 2*block_rows*D*4 B <= 160 KiB,
+ *                at D == 256 minus 4 KiB for the per-wave weight strips, i.e. <= 78)
  *   long_rows / partials as in wgnn_agg_fwd (every row of a column-split plan is a "long row").
  *   src_scratch: float[n_src * D], required for WGNN_SRC_IS_GENE: alpha is folded into the source rows
  *                once ((h*alpha), gnn.py:54) instead of once per edge.

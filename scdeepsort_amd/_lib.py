@@ -21,6 +21,7 @@ _vp, _i32, _i64, _u32, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_
 SIGNATURES = {
     "wgnn_version": (C.c_int, []),
     "wgnn_last_error_string": (C.c_char_p, [C.c_int]),
+    "wgnn_agg_workspace_bytes": (C.c_int, [_i64, _i64, _i32, _int, _int, _vp, _vp]),
     "wgnn_plan_build_host": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "wgnn_agg_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _int, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
                                _vp, _i64, _i64, _i32, _int, _int, _u32,

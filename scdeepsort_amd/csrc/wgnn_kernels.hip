@@ -187,6 +187,16 @@ extern "C" {
 
 int wgnn_version(void) { return WGNN_VERSION; }
 
+int wgnn_agg_workspace_bytes(int64_t n_partials, int64_t n_src, int32_t D, int alpha_mode, int tiled,
+                             int64_t* partials_bytes, int64_t* src_scratch_bytes) {
+    if (n_partials < 0 || n_src < 0 || D <= 0 || !partials_bytes || !src_scratch_bytes) return WGNN_ERR_BAD_ARG;
+    if (alpha_mode < WGNN_SRC_IS_GENE || alpha_mode > WGNN_NO_ALPHA) return WGNN_ERR_BAD_ARG;
+    if (D % 4) return WGNN_ERR_ALIGNMENT;
+    *partials_bytes = n_partials * (int64_t)D * 4;
+    *src_scratch_bytes = (tiled && alpha_mode == WGNN_SRC_IS_GENE) ? n_src * (int64_t)D * 4 : 0;
+    return WGNN_OK;
+}
+
 const char* wgnn_last_error_string(int code) {
     switch (code) {
         case WGNN_OK: return "ok";

@@ -121,3 +121,16 @@ def test_no_product_module_imports_the_oracle():
     for f in (ROOT / "scdeepsort_amd").rglob("*.py"):
         src = f.read_text()
         assert "oracle" not in re.sub(r'""".*?"""', "", src, flags=re.S).replace("# oracle", ""), f
+
+
+def test_workspace_query():
+    import ctypes as C
+    from scdeepsort_amd import _lib
+    lib = _lib.lib()
+    pb, sb = C.c_int64(), C.c_int64()
+    assert lib.wgnn_agg_workspace_bytes(10, 1000, 256, _lib.SRC_IS_GENE, 1, C.addressof(pb), C.addressof(sb)) == 0
+    assert (pb.value, sb.value) == (10 * 256 * 4, 1000 * 256 * 4)
+    assert lib.wgnn_agg_workspace_bytes(0, 1000, 64, _lib.DST_IS_GENE, 1, C.addressof(pb), C.addressof(sb)) == 0
+    assert (pb.value, sb.value) == (0, 0)
+    assert lib.wgnn_agg_workspace_bytes(1, 1, 6, 0, 0, C.addressof(pb), C.addressof(sb)) == -2      # WGNN_ERR_ALIGNMENT
+    assert lib.wgnn_agg_workspace_bytes(-1, 1, 8, 0, 0, C.addressof(pb), C.addressof(sb)) == -1     # WGNN_ERR_BAD_ARG
