@@ -224,6 +224,55 @@ def test_full_size_properties_cfg2():
     np.testing.assert_allclose(g.gc.val.cpu().numpy(), cg.A_gc.data, rtol=3e-6)
 
 
+def test_full_size_properties_cfg3():
+    """At BASELINE cfg3 size (the bench workload, LDS-streamed kernel): size-independent properties -
+    linearity in h, determinism, a row sample against the row-wave kernel, and a "checksum of checksums":
+    with h = 1 every output element must equal (sum_j w_j*alpha[k_j] + alpha_self) / (deg+1), computed here with
+    plain torch scatter-adds over the CSR."""
+    from scdeepsort_amd import ops, synthetic as S
+    cfg = S.CONFIGS["cfg3"]
+    G, C, H = cfg.genes, cfg.cells, cfg.hidden
+    rp, col, val = S.synth_expression(C, G, device=DEV)
+    g = sda.CellGeneGraph.from_device_csr(rp, col, val, G)
+    del rp, col, val
+    alpha = torch.rand(G + 2, device=DEV) + 0.5
+    hg1, hc1 = S.synth_features(G, H, device=DEV), S.synth_features(C, H, seed=3, device=DEV)
+    hg2, hc2 = S.synth_features(G, H, seed=5, device=DEV), S.synth_features(C, H, seed=6, device=DEV)
+    ops.PROFILE = []
+    f = lambda a, b: sda.agg_fwd(g.cg, alpha, sda.SRC_IS_GENE, G + 1, a, b)
+    fg = lambda a, b: sda.agg_fwd(g.gc, alpha, sda.DST_IS_GENE, G, b, a)
+    z1, z2, z3 = f(hg1, hc1), f(hg2, hc2), f(2 * hg1 - 0.5 * hg2, 2 * hc1 - 0.5 * hc2)
+    y1, y2, y3 = fg(hg1, hc1), fg(hg2, hc2), fg(2 * hg1 - 0.5 * hg2, 2 * hc1 - 0.5 * hc2)
+    kernels = {dict(zip(t[::2], t[1::2]))["kernel"] for t, _, _ in ops.PROFILE}
+    ops.PROFILE = None
+    assert kernels == {"agg_tiled_flat4"}
+    assert (2 * z1 - 0.5 * z2 - z3).abs().max().item() < 1e-4
+    assert (2 * y1 - 0.5 * y2 - y3).abs().max().item() < 1e-4
+    assert torch.equal(z1, f(hg1, hc1)) and torch.equal(y1, fg(hg1, hc1))          # deterministic (no atomics)
+    ids = torch.randperm(C, device=DEV)[:1000]
+    sub = sda.agg_fwd(g.cg, alpha, sda.SRC_IS_GENE, G + 1, hg1, hc1, row_ids=ids)    # row-wave kernel (K1)
+    assert (sub - z1[ids]).abs().max().item() < 1e-4
+    gids = torch.randperm(G, device=DEV)[:1000]
+    subg = sda.agg_fwd(g.gc, alpha, sda.DST_IS_GENE, G, hc1, hg1, row_ids=gids)
+    assert (subg - y1[gids]).abs().max().item() < 1e-4
+    # checksum: constant features
+    ones_g, ones_c = torch.ones(G, H, device=DEV), torch.ones(C, H, device=DEV)
+    zc, zg = f(ones_g, ones_c), fg(ones_g, ones_c)
+    a64 = alpha.double()
+    row_c = torch.repeat_interleave(torch.arange(C, device=DEV), (g.cg.rowptr[1:] - g.cg.rowptr[:-1]).long())
+    want_c = torch.zeros(C, dtype=torch.float64, device=DEV).index_add_(0, row_c, g.cg.val.double() * a64[g.cg.col.long()])
+    want_c = (want_c + a64[G + 1]) * g.cg.inv_deg.double()
+    row_g = torch.repeat_interleave(torch.arange(G, device=DEV), (g.gc.rowptr[1:] - g.gc.rowptr[:-1]).long())
+    want_g = torch.zeros(G, dtype=torch.float64, device=DEV).index_add_(0, row_g, g.gc.val.double())
+    want_g = (a64[:G] * want_g + a64[G]) * g.gc.inv_deg.double()
+    assert (zc.double() - want_c[:, None]).abs().max().item() < 1e-4
+    assert (zg.double() - want_g[:, None]).abs().max().item() < 1e-4
+    # the normalisation itself: every non-empty row's weights sum to its in-degree (preprocess_internal.py:17-23)
+    deg_c = (g.cg.rowptr[1:] - g.cg.rowptr[:-1]).double()
+    sum_c = torch.zeros(C, dtype=torch.float64, device=DEV).index_add_(0, row_c, g.cg.val.double())
+    assert (sum_c - deg_c).abs().max().item() < 1e-2 and ((sum_c - deg_c).abs() / deg_c.clamp(min=1)).max().item() < 1e-5
+
+
 # ---- LDS-streamed (tiled) kernel: same outputs as the oracle, every geometry -------------------
 @pytest.mark.parametrize("D", [64, 128, 256])
 @pytest.mark.parametrize("geom", [(None, 1), (3, 1), (2, 4), (5, 7)])
