@@ -100,33 +100,43 @@ class LocalOps:
 
 
 def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local: torch.Tensor, ops: LocalOps,
-                    n_layers: int, gather_logits: bool = True, shard_sizes: Optional[Sequence[int]] = None) -> torch.Tensor:
+                    n_layers: int, gather_logits: bool = True, shard_sizes: Optional[Sequence[int]] = None,
+                    async_gather: bool = False):
     """Layer-wise forward over a cell shard.  ``weights`` = list of (W_i, b_i) + (W_out, b_out) last.
     Features may be stored in fp16 (BASELINE cfg5): they are widened on the way into the fp32 projection, i.e. the
     arithmetic is "fp16-rounded inputs, fp32 accumulate".  ``shard_sizes`` (cells per rank, known at graph build)
-    lets the logits concat run without a size exchange / host sync."""
+    lets the logits concat run without a size exchange / host sync; with ``async_gather`` (equal shards only) the
+    concat is left running on the communicator's stream and ``(logits_all, work)`` is returned - the caller waits on
+    ``work`` before reading, so the output collection of one batch overlaps the next batch's compute."""
     h_g, h_c = feats_g, feats_c_local
     for i in range(n_layers):
         W, b = weights[i]
         last = i == n_layers - 1
         p_g = torch.nn.functional.linear(h_g.to(W.dtype), W)
         p_c = torch.nn.functional.linear(h_c.to(W.dtype), W)
-        new_c = ops.cells_layer(p_g, p_c, b, True)
-        if not last:
-            part = ops.genes_partial(p_c)
-            if torch.is_grad_enabled() and part.requires_grad:
-                part = all_reduce_sum(part)             # differentiable: backward all-reduces dH1_g
-            else:
-                all_reduce_sum_(part)                   # the ONE data-path collective (X2, SURVEY 8e)
-            h_g = ops.genes_finish(part, p_g, b, True)
+        if last:
+            h_c = ops.cells_layer(p_g, p_c, b, True)
+            break
+        part = ops.genes_partial(p_c)
+        if torch.is_grad_enabled() and part.requires_grad:
+            new_c = ops.cells_layer(p_g, p_c, b, True)
+            part = all_reduce_sum(part)                 # differentiable: backward all-reduces dH1_g
+        else:
+            # the ONE data-path collective (X2, SURVEY 8e) runs on the communicator's stream while this rank's
+            # cells<-genes pass (row-independent, no communication) computes
+            work = dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=True) if world()[1] > 1 else None
+            new_c = ops.cells_layer(p_g, p_c, b, True)
+            if work is not None:
+                work.wait()                             # stream-level dependency on GPU backends, no host sync
+        h_g = ops.genes_finish(part, p_g, b, True)
         h_c = new_c
     Wo, bo = weights[n_layers]
     logits = torch.nn.functional.linear(h_c, Wo, bo)
     rank, ws = world()
     if gather_logits and ws > 1 and shard_sizes is not None and len(set(shard_sizes)) == 1:
         out = torch.empty((ws * logits.shape[0], logits.shape[1]), dtype=logits.dtype, device=logits.device)
-        dist.all_gather_into_tensor(out, logits.contiguous())           # X3: inference concat, equal shards
-        return out
+        work = dist.all_gather_into_tensor(out, logits.contiguous(), async_op=async_gather)    # X3: inference concat
+        return (out, work) if async_gather else out
     if gather_logits and ws > 1:
         if shard_sizes is not None:
             mx = max(shard_sizes)
@@ -134,7 +144,8 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
             pad[: logits.shape[0]] = logits
             outs = [torch.empty_like(pad) for _ in range(ws)]
             dist.all_gather(outs, pad)
-            return torch.cat([o[:n] for o, n in zip(outs, shard_sizes)])
+            cat = torch.cat([o[:n] for o, n in zip(outs, shard_sizes)])
+            return (cat, None) if async_gather else cat
         sizes = [torch.zeros(1, dtype=torch.long, device=logits.device) for _ in range(ws)]
         dist.all_gather(sizes, torch.tensor([logits.shape[0]], dtype=torch.long, device=logits.device))
         mx = int(max(s.item() for s in sizes))
@@ -143,7 +154,7 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
         outs = [torch.empty_like(pad) for _ in range(ws)]
         dist.all_gather(outs, pad)                      # X3: inference concat
         logits = torch.cat([o[: int(s.item())] for o, s in zip(outs, sizes)])
-    return logits
+    return (logits, None) if async_gather else logits
 
 
 def all_reduce_grads(params) -> None:

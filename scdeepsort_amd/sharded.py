@@ -94,12 +94,25 @@ class ShardedWgnn:
         return D.sharded_train_step(list(self.model.parameters()), self._weights, feats_g, feats_c_local, labels_local,
                                     self._ops(), self.model.n_layers, optimizer, seeds_local)
 
-    def forward(self, feats_g: torch.Tensor, feats_c_local: torch.Tensor, gather_logits: bool = True) -> torch.Tensor:
+    def forward(self, feats_g: torch.Tensor, feats_c_local: torch.Tensor, gather_logits: bool = True,
+                async_gather: bool = False) -> torch.Tensor:
+        """Logits of every cell of the job (``gather_logits``) or of this rank's cells.  ``async_gather``: the concat of
+        this call is left in flight (it overlaps the next call's compute); ``wait_gather()`` - called automatically at
+        the start of the next forward - completes it before the returned tensor may be read."""
         m = self.model
         if self.world == 1:
             return m.linear(m.embed(self.graph, (feats_g, feats_c_local)))
-        return D.sharded_forward(self._weights(), None, feats_g, feats_c_local, self._ops(), m.n_layers, gather_logits,
-                                 self.shard_sizes)
+        self.wait_gather()
+        res = D.sharded_forward(self._weights(), None, feats_g, feats_c_local, self._ops(), m.n_layers, gather_logits,
+                                self.shard_sizes, async_gather)
+        if async_gather:
+            res, self._pending = res
+        return res
+
+    def wait_gather(self) -> None:
+        work, self._pending = getattr(self, "_pending", None), None
+        if work is not None:
+            work.wait()
 
     def forward_alg_bytes(self, dense_dim: int, s0: int = 4) -> int:
         """Algorithmic HBM bytes of one 2-layer forward on this rank (SURVEY.md section 8d formula); ``s0`` = bytes per

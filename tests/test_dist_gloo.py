@@ -74,6 +74,10 @@ def _worker(rank, world, port, out_dir, cells=90):
         sizes = [D.shard_range(C, r, world)[1] - D.shard_range(C, r, world)[0] for r in range(world)]
         l2 = D.sharded_forward(weights, None, feats[:G], feats[G + lo:G + hi], ops, 2, True, sizes)
         assert torch.equal(l2, logits)
+        res = D.sharded_forward(weights, None, feats[:G], feats[G + lo:G + hi], ops, 2, True, sizes, async_gather=True)
+        if res[1] is not None:
+            res[1].wait()
+        assert torch.equal(res[0], logits)
         # fp16-stored features (cfg5): widened on the way into the projection
         f16 = feats.half()
         l3 = D.sharded_forward(weights, None, f16[:G], f16[G + lo:G + hi], ops, 2, True, sizes)
