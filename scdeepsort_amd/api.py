@@ -57,6 +57,69 @@ def _features(expr: sp.csr_matrix, n_support: int, dense_dim: int, seed, device)
     return torch.cat([gf, cf])
 
 
+def read_xlsx_sheet(path, sheet_name: str) -> List[List[Optional[str]]]:
+    """Rows of one worksheet of an .xlsx workbook as lists of strings (None = empty cell).  A minimal reader (zip + XML,
+    shared and inline strings, plain numbers) for ``map/celltype2subtype.xlsx`` (predict.py:125-128): neither xlrd nor
+    openpyxl is a dependency here."""
+    import re
+    import zipfile
+    import xml.etree.ElementTree as ET
+    ns = {"m": "http://schemas.openxmlformats.org/spreadsheetml/2006/main",
+          "r": "http://schemas.openxmlformats.org/officeDocument/2006/relationships"}
+    with zipfile.ZipFile(path) as z:
+        wb = ET.fromstring(z.read("xl/workbook.xml"))
+        rid = None
+        for sh in wb.find("m:sheets", ns):
+            if sh.get("name") == sheet_name:
+                rid = sh.get(f"{{{ns['r']}}}id")
+        if rid is None:
+            raise KeyError(f"no sheet {sheet_name!r} in {path}")
+        rels = ET.fromstring(z.read("xl/_rels/workbook.xml.rels"))
+        target = next(r.get("Target") for r in rels if r.get("Id") == rid)
+        target = target.lstrip("/")
+        target = target if target.startswith("xl/") else "xl/" + target
+        shared: List[str] = []
+        if "xl/sharedStrings.xml" in z.namelist():
+            for si in ET.fromstring(z.read("xl/sharedStrings.xml")).findall("m:si", ns):
+                shared.append("".join(t.text or "" for t in si.iter(f"{{{ns['m']}}}t")))
+        rows: List[List[Optional[str]]] = []
+        for row in ET.fromstring(z.read(target)).find("m:sheetData", ns).findall("m:row", ns):
+            cells: List[Optional[str]] = []
+            for c in row.findall("m:c", ns):
+                letters = re.match(r"[A-Z]+", c.get("r", "A")).group(0)
+                col = 0
+                for ch in letters:
+                    col = col * 26 + ord(ch) - 64
+                while len(cells) < col:
+                    cells.append(None)
+                v, t = c.find("m:v", ns), c.get("t")
+                if t == "s" and v is not None:
+                    val = shared[int(v.text)]
+                elif t == "inlineStr":
+                    val = "".join(x.text or "" for x in c.iter(f"{{{ns['m']}}}t"))
+                else:
+                    val = v.text if v is not None else None
+                cells[col - 1] = val
+            rows.append(cells)
+        return rows
+
+
+_PANDAS_NA = {"", "#N/A", "#N/A N/A", "#NA", "-1.#IND", "-1.#QNAN", "-NaN", "-nan", "1.#IND", "1.#QNAN", "<NA>", "N/A", "NA",
+              "NULL", "NaN", "None", "n/a", "nan", "null"}
+
+
+def load_label_map(path, species: str) -> Tuple[dict, dict]:
+    """old cell type -> (new type, new subtype) from the ``species`` sheet of celltype2subtype.xlsx; empty cells become
+    'N/A' (predict.py:125-133)."""
+    old2new, old2sub = {}, {}
+    for row in read_xlsx_sheet(path, species)[1:]:                     # header=0
+        row = (row + [None] * 4)[:4]
+        # pandas.read_excel parses its default NA strings as NaN, which the reference then fills with 'N/A'
+        _, old, new, sub = [("N/A" if x is None or x in _PANDAS_NA else x) for x in row]
+        old2new[old], old2sub[old] = new, sub
+    return old2new, old2sub
+
+
 def _classify(logits: torch.Tensor, unsure_rate: float) -> Tuple[np.ndarray, np.ndarray]:
     """softmax -> 'unsure' iff max_prob < unsure_rate/num_classes, else argmax (predict.py:78-88)."""
     prob = F.softmax(logits.float(), dim=1)
@@ -206,7 +269,13 @@ def _predict(species, tissue, input_file, model_path: Path, save_path, unsure_ra
     seeds = torch.arange(G + n_sup, G + expr.shape[0], device=dev)
     with torch.no_grad():
         pred, _ = _classify(model(graph, feats, seeds=seeds), unsure_rate)
-    out = pd.DataFrame({"index": df.index, "cell_type": [id2label[p] if p >= 0 else "unsure" for p in pred]})
+    names = [id2label[p] if p >= 0 else "unsure" for p in pred]
+    out = pd.DataFrame({"index": df.index, "cell_type": names})
+    map_file = next((f for f in (model_path / "celltype2subtype.xlsx", Path("map") / "celltype2subtype.xlsx") if f.exists()), None)
+    if map_file is not None:                                             # predict.py:124-146: new type / subtype names
+        old2new, old2sub = load_label_map(map_file, species)
+        out = pd.DataFrame({"index": df.index, "cell_type": [old2new.get(p, p) for p in names],
+                            "cell_subtype": [old2sub.get(p, p) for p in names]})
     if save_path is not None:
         Path(save_path).mkdir(parents=True, exist_ok=True)
         out.to_csv(Path(save_path) / f"{species}_{tissue}_{Path(input_file).stem}.csv", index=False)

@@ -83,6 +83,15 @@ def test_fit_predict_roundtrip(tmp_path):
     out2 = sda.DeepSortPredictor("mouse", "Demo").predict(dt, model_path=tmp_path / "bundle")
     assert out2["cell_type"].tolist() == out["cell_type"].tolist()
     assert (tmp_path / "result").exists()
+    # with the label map in the bundle the output carries the new type / subtype names (predict.py:124-146)
+    _write_xlsx(tmp_path / "bundle" / "celltype2subtype.xlsx",
+                {"mouse": [["Species", "Cell type", "Cell-type", "Cell-subtype"], ["Mouse", "type0", "Zero", "zero-a"],
+                           ["Mouse", "type1", "One", None]]})
+    out3 = clf.predict(dt, model_path=tmp_path / "bundle")
+    assert list(out3.columns) == ["index", "cell_type", "cell_subtype"]
+    want_t = {"type0": "Zero", "type1": "One"}; want_s = {"type0": "zero-a", "type1": "N/A"}
+    assert out3["cell_type"].tolist() == [want_t.get(p, p) for p in out["cell_type"]]
+    assert out3["cell_subtype"].tolist() == [want_s.get(p, p) for p in out["cell_type"]]
 
 
 @pytest.mark.gpu
@@ -100,3 +109,49 @@ def test_fit_with_neighbour_subsampling(tmp_path):
     clf.fit([(d1, c1)])
     assert clf.num_neighbors == 8
     assert max(h["val_acc"] for h in clf.history) > 0.8
+
+
+def _write_xlsx(path, sheets):
+    """Minimal .xlsx (shared strings only) written with zipfile: {sheet name: rows of str | None}."""
+    import zipfile
+    from xml.sax.saxutils import escape
+    strings, index = [], {}
+    def sid(s):
+        if s not in index:
+            index[s] = len(strings); strings.append(s)
+        return index[s]
+    sheet_xml = {}
+    for n, (name, rows) in enumerate(sheets.items(), 1):
+        body = []
+        for r, row in enumerate(rows, 1):
+            cells = "".join(f'<c r="{chr(64 + c)}{r}" t="s"><v>{sid(v)}</v></c>' for c, v in enumerate(row, 1) if v is not None)
+            body.append(f'<row r="{r}">{cells}</row>')
+        sheet_xml[n] = ('<?xml version="1.0" encoding="UTF-8"?><worksheet xmlns="http://schemas.openxmlformats.org/spreadsheetml/2006/main">'
+                        f'<sheetData>{"".join(body)}</sheetData></worksheet>')
+    ns = 'xmlns="http://schemas.openxmlformats.org/spreadsheetml/2006/main" xmlns:r="http://schemas.openxmlformats.org/officeDocument/2006/relationships"'
+    with zipfile.ZipFile(path, "w") as z:
+        z.writestr("xl/workbook.xml", f'<?xml version="1.0"?><workbook {ns}><sheets>' + "".join(
+            f'<sheet name="{name}" sheetId="{n}" r:id="rId{n}"/>' for n, name in enumerate(sheets, 1)) + "</sheets></workbook>")
+        z.writestr("xl/_rels/workbook.xml.rels", '<?xml version="1.0"?><Relationships xmlns="http://schemas.openxmlformats.org/package/2006/relationships">' + "".join(
+            f'<Relationship Id="rId{n}" Type="http://schemas.openxmlformats.org/officeDocument/2006/relationships/worksheet" Target="worksheets/sheet{n}.xml"/>'
+            for n in sheet_xml) + "</Relationships>")
+        z.writestr("xl/sharedStrings.xml", '<?xml version="1.0"?><sst xmlns="http://schemas.openxmlformats.org/spreadsheetml/2006/main">' +
+                   "".join(f"<si><t>{escape(s)}</t></si>" for s in strings) + "</sst>")
+        for n, xml in sheet_xml.items():
+            z.writestr(f"xl/worksheets/sheet{n}.xml", xml)
+
+
+def test_label_map_reader(tmp_path):
+    """celltype2subtype.xlsx (predict.py:124-133): per-species sheet, old type -> (new type, new subtype), blanks and
+    pandas' NA strings -> 'N/A'."""
+    from scdeepsort_amd.api import load_label_map, read_xlsx_sheet
+    f = tmp_path / "celltype2subtype.xlsx"
+    _write_xlsx(f, {"human": [["Species", "Cell type", "Cell-type", "Cell-subtype"], ["Human", "T cell", "T cell", "NA"]],
+                    "mouse": [["Species", "Cell type", "Cell-type", "Cell-subtype"],
+                              ["Mouse", "type0", "Alpha & beta", "sub<0>"], ["Mouse", "type1", "Beta", None], ["Mouse", "type2", "Gamma", "NA"]]})
+    assert read_xlsx_sheet(f, "human")[1] == ["Human", "T cell", "T cell", "NA"]
+    new, sub = load_label_map(f, "mouse")
+    assert new == {"type0": "Alpha & beta", "type1": "Beta", "type2": "Gamma"}
+    assert sub == {"type0": "sub<0>", "type1": "N/A", "type2": "N/A"}
+    with pytest.raises(KeyError):
+        read_xlsx_sheet(f, "rat")
