@@ -255,6 +255,14 @@ def test_full_size_properties_cfg3():
     gids = torch.randperm(G, device=DEV)[:1000]
     subg = sda.agg_fwd(g.gc, alpha, sda.DST_IS_GENE, G, hc1, hg1, row_ids=gids)
     assert (subg - y1[gids]).abs().max().item() < 1e-4
+    # independent formulation at full size: torch's CSR SpMM (hipSPARSE) + elementwise epilogue, fp32
+    A_cg = torch.sparse_csr_tensor(g.cg.rowptr.long(), g.cg.col.long(), g.cg.val, size=(C, G))
+    ref_c = (torch.sparse.mm(A_cg, alpha[:G, None] * hg1) + alpha[G + 1] * hc1) * g.cg.inv_deg[:, None]
+    assert (ref_c - z1).abs().max().item() < 1e-4
+    A_gc = torch.sparse_csr_tensor(g.gc.rowptr.long(), g.gc.col.long(), g.gc.val, size=(G, C))
+    ref_g = (alpha[:G, None] * torch.sparse.mm(A_gc, hc1) + alpha[G] * hg1) * g.gc.inv_deg[:, None]
+    assert (ref_g - y1).abs().max().item() < 1e-4
+    del A_cg, A_gc, ref_c, ref_g
     # checksum: constant features
     ones_g, ones_c = torch.ones(G, H, device=DEV), torch.ones(C, H, device=DEV)
     zc, zg = f(ones_g, ones_c), fg(ones_g, ones_c)
