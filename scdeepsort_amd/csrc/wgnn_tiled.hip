@@ -195,11 +195,6 @@ __global__ void __launch_bounds__(kTW * 64) agg_tiled(const KArgs a, const TArgs
 // VMEM issue order inside block b:  S(b+3), DMA pieces of block b+1, E(b+2)   =>  at the top of block b+1 everything
 // but E(b+2) must have landed: s_waitcnt vmcnt(1).  An entry chunk therefore has two block times to arrive.
 // ---------------------------------------------------------------------------------------------
-template <int SET> __device__ __forceinline__ void chunk_load(const int2* p) {
-    if constexpr (SET == 0) asm volatile("global_load_dwordx2 v[34:35], %0, off" ::"v"(p) : "memory", "v34", "v35");
-    if constexpr (SET == 1) asm volatile("global_load_dwordx2 v[36:37], %0, off" ::"v"(p) : "memory", "v36", "v37");
-    if constexpr (SET == 2) asm volatile("global_load_dwordx2 v[38:39], %0, off" ::"v"(p) : "memory", "v38", "v39");
-}
 template <int SET> __device__ __forceinline__ int2 chunk_get() {
     int2 e;
     if constexpr (SET == 0) asm volatile("v_mov_b32 %0, v34\n\tv_mov_b32 %1, v35" : "=v"(e.x), "=v"(e.y)::"memory");
@@ -208,7 +203,7 @@ template <int SET> __device__ __forceinline__ int2 chunk_get() {
     return e;
 }
 
-template <typename TOut, int EPI>
+template <typename TOut, int EPI, bool DBG>
 __global__ void __launch_bounds__(kTW * 64) __attribute__((amdgpu_num_vgpr(32), amdgpu_num_sgpr(80)))
 agg_tiled_flat4(const KArgs a, const TArgs t) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -221,36 +216,51 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
     const int cb = __builtin_amdgcn_readfirstlane(hdr.x), ce = __builtin_amdgcn_readfirstlane(hdr.y);
     const int nblk = (ce - cb + kKB - 1) / kKB;
     const int* seg = t.seg_ptr + ((size_t)tile * t.nblk_max) * kTW + wave;     // seg[b*16], seg[b*16+1]
-    const bool do_fill = !(a.flags & kDbgNoFill), do_comp = !(a.flags & kDbgNoCompute);
-    const bool do_barrier = !(a.flags & kDbgNoBarrier);
+    const unsigned dbg = DBG ? a.flags : 0u;             // ablation switches exist in the DBG instantiation only
+    const bool do_fill = !(dbg & kDbgNoFill), do_comp = !(dbg & kDbgNoCompute), do_barrier = !(dbg & kDbgNoBarrier);
 
     for (int r = 0; r < kRPW; ++r)                       // zero the accumulators v[64:127]
         asm volatile("s_set_gpr_idx_on %0, gpr_idx(DST)\n\tv_mov_b32 v64, 0\n\tv_mov_b32 v65, 0\n\t"
                      "v_mov_b32 v66, 0\n\tv_mov_b32 v67, 0\n\ts_set_gpr_idx_off" ::"s"(r * 4) : WGNN_CLOB);
 
-    // global -> LDS DMA of source block b into buffer b&1: one 1 KiB row per wave-instruction
-    auto fill = [&](int b) {
-        const int r0 = cb + b * kKB;
-        const int nbytes = min(kKB, ce - r0) * row_bytes;
-        const char* g = reinterpret_cast<const char*>(a.src) + (size_t)r0 * row_bytes + lane * 16;
-        const int l = (int)(size_t)smem + (b & 1) * buf_bytes;
-        for (int p = wave; p * 1024 < nbytes; p += kTW)
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g + p * 1024), "s"(l + p * 1024)
-                         : "m0", "memory");
+    const int lane16 = lane * 16, row_mask = ~1023;
+    // global -> LDS DMA of `rows` source rows starting at global row r0 into LDS buffer `buf`: one 1 KiB row per
+    // wave-instruction, wave w takes rows w, w+16, ...  Scalar base + lane offset addressing: no VALU, 4 SALU per row.
+    auto fill_rows = [&](int r0, int rows, int buf) {
+        const int np = rows > wave ? (rows - wave + kTW - 1) / kTW : 0;        // <= 5 for blocks of <= 80 rows
+        if (np == 0) return;
+        const char* g = reinterpret_cast<const char*>(a.src) + ((size_t)r0 + wave) * row_bytes;
+        const int l = (int)(size_t)smem + buf * buf_bytes + wave * row_bytes;
+#define WGNN_FILL_NEXT(K)                                                                                   \
+        "s_cmp_lt_u32 %[np], " #K "\n\ts_cbranch_scc1 .Lw4_fd_%=\n\t"                                        \
+        "s_add_u32 m0, m0, 0x4000\n\ts_add_u32 s94, s94, 0x4000\n\ts_addc_u32 s95, s95, 0\n\t"               \
+        "global_load_lds_dwordx4 %[vo], s[94:95]\n\t"
+        asm volatile("s_mov_b64 s[94:95], %[g]\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\t"
+                     "global_load_lds_dwordx4 %[vo], s[94:95]\n\t"
+                     WGNN_FILL_NEXT(2) WGNN_FILL_NEXT(3) WGNN_FILL_NEXT(4) WGNN_FILL_NEXT(5)
+                     ".Lw4_fd_%=:"
+                     ::[g] "s"(g), [l] "s"(l), [vo] "v"(lane16), [np] "s"(np)
+                     : "m0", "memory", "scc", "s94", "s95");
+#undef WGNN_FILL_NEXT
     };
+    auto fill = [&](int b) { fill_rows(cb + b * kKB, min(kKB, ce - (cb + b * kKB)), b & 1); };
     // RIGHT-aligned entry chunk of segment [s, e): with n = min(64, e - s) entries, lane j <- entry s + j - (64 - n);
-    // the lanes in front of the chunk replicate a valid entry (consume() zeroes their weight).  Always issues exactly
-    // one load (the vmcnt bookkeeping depends on it), also for an empty segment.
-    auto chunk_addr = [&](int s, int e) {
-        const int idx = min(max(s + lane - (64 - min(64, e - s)), s), max(e - 1, 0));
-        return t.entries + idx;
+    // the lanes in front of the chunk replicate its first entry (consume() zeroes their weight).  Always issues exactly
+    // one load (the vmcnt bookkeeping depends on it), also for an empty segment (then: any valid entry).
+    auto chunk_issue = [&](auto set, int s, int e) {
+        constexpr int SET = decltype(set)::value;
+        const int n = min(64, e - s);
+        const int2* base = t.entries + (n > 0 ? s : max(e - 1, 0));
+        const int off = max(lane - (64 - n), 0) * 8;                          // n == 0: 0
+        if constexpr (SET == 0) asm volatile("global_load_dwordx2 v[34:35], %0, %1" ::"v"(off), "s"(base) : "memory", "v34", "v35");
+        if constexpr (SET == 1) asm volatile("global_load_dwordx2 v[36:37], %0, %1" ::"v"(off), "s"(base) : "memory", "v36", "v37");
+        if constexpr (SET == 2) asm volatile("global_load_dwordx2 v[38:39], %0, %1" ::"v"(off), "s"(base) : "memory", "v38", "v39");
     };
-    auto seg_load = [&](int b) {                          // -> v[32:33]
-        asm volatile("global_load_dwordx2 v[32:33], %0, off" ::"v"(seg + b * kTW) : "memory", "v32", "v33");
+    auto seg_load = [&](const int* p) {                   // {begin, end} of one (block, wave) -> v[32:33]
+        asm volatile("global_load_dwordx2 v[32:33], %0, %1" ::"v"(0), "s"(p) : "memory", "v32", "v33");
     };
     // n (1..64) entries of one chunk -> the generated straight-line pipeline.  The weights go through the wave's
     // 256-byte LDS strip (behind the two row buffers) and come back as broadcast reads.
-    const int lane16 = lane * 16, row_mask = ~1023;
     const int wstrip_addr = (int)(size_t)smem + 2 * buf_bytes + wave * 256;
     const int wlane_addr = wstrip_addr + lane * 4;
     auto consume = [&](const int2& ent, int n, int buf_addr) {
@@ -264,28 +274,44 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
                        "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93",
                        "s94", "s95");
     };
-    // one source block.  CUR / NXT = register sets of blocks b / b+2; (cs, ce0) = this block's segment; (ns, ne) receive
-    // the segment of block b+2 (kept in SGPRs until that block is consumed).
+    auto compute = [&](auto cur_set, int cs, int ce0, int buf_addr) {
+        constexpr int CUR = decltype(cur_set)::value;
+        if (cs >= ce0) return;
+        consume(chunk_get<CUR>(), min(64, ce0 - cs), buf_addr);
+        for (int s = cs + 64; s < ce0; s += 64) {            // rare: more than 64 entries for this wave in one block
+            chunk_issue(cur_set, s, ce0);                   // (E(b+2) is in flight behind it: wait for both)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            consume(chunk_get<CUR>(), min(64, ce0 - s), buf_addr);
+        }
+    };
+    // One source block, general form.  CUR / NXT = register sets of blocks b / b+2; (cs, ce0) = this block's segment;
+    // (ns, ne) receive the segment of block b+2 (kept in SGPRs until that block is consumed).
     auto block = [&](auto cur_set, auto nxt_set, int b, int cs, int ce0, int& ns, int& ne) {
-        constexpr int CUR = decltype(cur_set)::value, NXT = decltype(nxt_set)::value;
         if (b + 1 < nblk) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");    // all but E(b+1): DMA of block b, E(b), S(b+2)
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (do_barrier) __builtin_amdgcn_s_barrier();       // everyone's DMA pieces landed; everyone is done with block b-1
         if (b + 2 < nblk) {
             asm volatile("v_readfirstlane_b32 %0, v32\n\tv_readfirstlane_b32 %1, v33" : "=s"(ns), "=s"(ne)::"memory");
-            if (b + 3 < nblk) seg_load(b + 3);
+            if (b + 3 < nblk) seg_load(seg + (b + 3) * kTW);
         }
         if (b + 1 < nblk && do_fill) fill(b + 1);
-        if (b + 2 < nblk) chunk_load<NXT>(chunk_addr(ns, ne));
-        const int buf_addr = (int)(size_t)smem + (b & 1) * buf_bytes;         // 1 KiB-aligned: smem is the only LDS object
-        if (do_comp && cs < ce0 && !((a.flags & (1u << 22)) && wave >= 8)) {   // bit 22 (timing experiment): half the waves idle
-            consume(chunk_get<CUR>(), min(64, ce0 - cs), buf_addr);
-            for (int s = cs + 64; s < ce0; s += 64) {        // rare: more than 64 entries for this wave in one block
-                chunk_load<CUR>(chunk_addr(s, ce0));        // (E(b+2) is in flight behind it: wait for both)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                consume(chunk_get<CUR>(), min(64, ce0 - s), buf_addr);
-            }
-        }
+        if (b + 2 < nblk) chunk_issue(nxt_set, ns, ne);
+        if (do_comp) compute(cur_set, cs, ce0, (int)(size_t)smem + (b & 1) * buf_bytes);   // smem: the only LDS object
+    };
+    // Steady state (b + 3 < nblk, so blocks b+1, b+2, b+3 exist and block b+1 is a full one): no range checks, the
+    // segment pointer / DMA source row / buffer parity advance incrementally.
+    const int* segp = seg + 3 * kTW;                         // -> segment of block b+3
+    int fill_row = cb + kKB;                                 // first source row of block b+1
+    auto fast_block = [&](auto cur_set, auto nxt_set, int par, int cs, int ce0, int& ns, int& ne) {
+        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        if (do_barrier) __builtin_amdgcn_s_barrier();
+        asm volatile("v_readfirstlane_b32 %0, v32\n\tv_readfirstlane_b32 %1, v33" : "=s"(ns), "=s"(ne)::"memory");
+        seg_load(segp);
+        segp += kTW;
+        if (do_fill) fill_rows(fill_row, kKB, par ^ 1);
+        fill_row += kKB;
+        chunk_issue(nxt_set, ns, ne);
+        if (do_comp) compute(cur_set, cs, ce0, (int)(size_t)smem + par * buf_bytes);
     };
 
     if (nblk > 0) {
@@ -293,11 +319,20 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
         cptr_t sseg = (cptr_t)seg;                        // the first two segments through the scalar cache
         int sA = sseg[0], eA = sseg[1], sB = 0, eB = 0, sC = 0, eC = 0;
         if (nblk > 1) { sB = sseg[kTW]; eB = sseg[kTW + 1]; }
-        if (nblk > 2) seg_load(2);
+        if (nblk > 2) seg_load(seg + 2 * kTW);
         if (do_fill) fill(0);
-        chunk_load<0>(chunk_addr(sA, eA));
-        if (nblk > 1) chunk_load<1>(chunk_addr(sB, eB));
-        for (int b = 0; b < nblk; b += 3) {                  // unrolled by three: the register sets rotate statically
+        chunk_issue(S0{}, sA, eA);
+        if (nblk > 1) chunk_issue(S1{}, sB, eB);
+        int b = 0;
+        for (; b + 5 < nblk; b += 6) {                       // six blocks per trip: register sets (x3) and buffer parity (x2) rotate statically
+            fast_block(S0{}, S2{}, 0, sA, eA, sC, eC);
+            fast_block(S1{}, S0{}, 1, sB, eB, sA, eA);
+            fast_block(S2{}, S1{}, 0, sC, eC, sB, eB);
+            fast_block(S0{}, S2{}, 1, sA, eA, sC, eC);
+            fast_block(S1{}, S0{}, 0, sB, eB, sA, eA);
+            fast_block(S2{}, S1{}, 1, sC, eC, sB, eB);
+        }
+        for (; b < nblk; b += 3) {                           // the last 3..8 blocks: general form
             block(S0{}, S2{}, b, sA, eA, sC, eC);
             if (b + 1 < nblk) block(S1{}, S0{}, b + 1, sB, eB, sA, eA);
             if (b + 2 < nblk) block(S2{}, S1{}, b + 2, sC, eC, sB, eB);
@@ -336,12 +371,17 @@ int launch_tiled(const KArgs& a, const TArgs& t, long n_tiles, hipStream_t st) {
     if (a.D == 256 && !(a.flags & (1u << 19))) {       // bit 19: force the generic (row-visit) kernel, for A/B timing
         static int flat_configured = 0;
         if (flat_configured < lds) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_tiled_flat4<TOut, EPI>),
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_tiled_flat4<TOut, EPI, false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_tiled_flat4<TOut, EPI, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
                 return WGNN_ERR_LAUNCH;
             flat_configured = lds;
         }
-        hipLaunchKernelGGL((agg_tiled_flat4<TOut, EPI>), dim3((unsigned)n_tiles), dim3(kTW * 64), lds, st, a, t);
+        if (a.flags & 0xFFFF0000u)                       // timing-experiment switches: the instantiation that reads them
+            hipLaunchKernelGGL((agg_tiled_flat4<TOut, EPI, true>), dim3((unsigned)n_tiles), dim3(kTW * 64), lds, st, a, t);
+        else
+            hipLaunchKernelGGL((agg_tiled_flat4<TOut, EPI, false>), dim3((unsigned)n_tiles), dim3(kTW * 64), lds, st, a, t);
     } else {
         hipLaunchKernelGGL((agg_tiled<TOut, EPI>), dim3((unsigned)n_tiles), dim3(kTW * 64), lds, st, a, t);
     }
