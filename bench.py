@@ -163,9 +163,20 @@ def main():
             traffic = json.loads(tf.read_text()).get(f"{args.config}:{dom['rows']}x{dom['src_rows']}")
         except Exception:
             traffic = None
+    # measured device copy bandwidth (read + write of a 1 GiB fp32 buffer), outside the timed region: the achievable HBM rate
+    src_buf = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=dev); dst_buf = torch.empty_like(src_buf)
+    dst_buf.copy_(src_buf); torch.cuda.synchronize()
+    ce0, ce1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ce0.record()
+    for _ in range(5):
+        dst_buf.copy_(src_buf)
+    ce1.record(); torch.cuda.synchronize()
+    copy_gbs = 5 * 2 * src_buf.numel() * 4 / (ce0.elapsed_time(ce1) * 1e-3) / 1e9
+    del src_buf, dst_buf
     roofline = {"bound": "hbm", "kernel": f"{dom['kernel']} (rows={dom['rows']}, src={dom['src_rows']}, D={dom['D']})",
                 "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "measured_copy_GBs": round(copy_gbs, 1), "frac_of_measured_copy": round(dom["achieved_GBs"] / copy_gbs, 4),
                 "alg_bytes_per_launch": dom["alg_bytes"], "avg_launch_ms": dom["avg_ms"], "passes": passes,
                 "forward_alg_bytes": engine.forward_alg_bytes(cfg.dense_dim, feats_g.element_size()),
                 "forward_achieved_GBs": round(engine.forward_alg_bytes(cfg.dense_dim, feats_g.element_size()) / ms_per_step / 1e6, 1),

@@ -308,6 +308,35 @@ def test_tiled_kernel_matches_oracle(D, geom, direction, kb):
     np.testing.assert_allclose(out.cpu().numpy(), want, atol=TOL)
 
 
+@pytest.mark.parametrize("kb", [16, 17, 19, 23, 31])
+@pytest.mark.parametrize("direction", ["cells", "genes"])
+def test_flat_kernel_many_blocks(kb, direction):
+    """D = 256 with short LDS blocks: 40-125 source blocks per tile, so the six-block steady-state loop of
+    agg_tiled_flat4 and every tail length (blocks mod 6) run; chunks longer than 64 entries (hub genes) too."""
+    from scdeepsort_amd.graph import build_tile_plan
+    from scdeepsort_amd import ops
+    c = small_case(cells=1500, genes=700, dim=256, seed=kb, density=0.12, test_cells=30)
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
+    cg = O.build_csr_graph(c["expr"], c["support_mask"])
+    G = c["G"]; rng = np.random.default_rng(kb)
+    alpha = rng.uniform(0.5, 1.5, G + 2).astype(np.float32)
+    Hg, Hc = c["feats"][:G], c["feats"][G:]
+    zc, zg = O.csr_aggregate(cg, alpha, Hg.astype(np.float64), Hc.astype(np.float64))
+    ops.PROFILE = []
+    if direction == "cells":
+        tp = build_tile_plan(g.cg, 6, 1, block_rows=kb)
+        out = ops.agg_fwd_tiled(g.cg, tp, dev(alpha), sda.SRC_IS_GENE, G + 1, dev(Hg), dev(Hc))
+        want = zc
+    else:
+        tp = build_tile_plan(g.gc, 3, 2, block_rows=kb)
+        out = ops.agg_fwd_tiled(g.gc, tp, dev(alpha), sda.DST_IS_GENE, G, dev(Hc), dev(Hg))
+        want = zg
+    kernels = {dict(zip(t[::2], t[1::2]))["kernel"] for t, _, _ in ops.PROFILE}
+    ops.PROFILE = None
+    assert kernels == {"agg_tiled_flat4"}
+    np.testing.assert_allclose(out.cpu().numpy(), want, atol=TOL)
+
+
 def test_tiled_plan_covers_every_edge_once():
     from scdeepsort_amd.graph import build_tile_plan
     c = small_case(cells=600, genes=300, seed=3, density=0.2)
