@@ -12,9 +12,11 @@ def timeit(f,n=20):
     f(); torch.cuda.synchronize(); t=time.perf_counter()
     for _ in range(n): f()
     torch.cuda.synchronize(); return (time.perf_counter()-t)/n*1e3
-tpc=g.cg.tile_plan(78)
 B=lambda *bits: sum(1<<b for b in bits)
-for rep in range(2):
-  for nm,fl in [('16w nofill+nobar',B(16,18)),('8w nofill+nobar',B(16,18,22)),('16w full',0),('8w full',B(22)),('16w nofill',B(16)),('8w nofill',B(16,22))]:
-    ops.DEBUG_FLAGS=fl
-    print(f"{nm:20s} {timeit(lambda: ops.agg_fwd_tiled(g.cg,tpc,alpha,sda.SRC_IS_GENE,G+1,hg,hc)):.3f}", flush=True)
+for kb in (78, 64, 48, 32):
+    tpc=g.cg.tile_plan(kb)
+    out=[]
+    for nm,fl in [('full',0),('nocompute',B(17)),('nocompute+nobar',B(17,18)),('nofill',B(16))]:
+        ops.DEBUG_FLAGS=fl
+        out.append(f"{nm} {timeit(lambda: ops.agg_fwd_tiled(g.cg,tpc,alpha,sda.SRC_IS_GENE,G+1,hg,hc)):.3f}")
+    print(f"kb {kb}: "+' | '.join(out), flush=True)
