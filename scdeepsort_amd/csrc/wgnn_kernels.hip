@@ -60,22 +60,35 @@ __global__ void __launch_bounds__(kBlock) agg_main(const KArgs a) {
         if (base + 64 < end) fetch(base + 64, c_nxt, w_nxt);          // software prefetch of the next tile
         const int n = min(64, end - base);
         const int steps = (n + G - 1) / G;
-#pragma unroll 4
-        for (int j = 0; j < steps; ++j) {
-            int c; float w;
-            if constexpr (G == 1) {
-                c = __builtin_amdgcn_readlane(c_cur, j);
-                w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w_cur), j));
-            } else {
-                c = __shfl(c_cur, j * G + sub, 64);
-                w = __shfl(w_cur, j * G + sub, 64);
-            }
-            const TIn* p = src + (size_t)c * a.ld_src;
+        // U gathers in flight per lane before the first FMA (the loop is otherwise bound by one L2 round trip per
+        // non-zero); steps past the end re-read the last row with weight 0.
+        constexpr int U = NV >= 4 ? 2 : (NV >= 2 ? 4 : 8);
+        for (int j0 = 0; j0 < steps; j0 += U) {
+            float4 x[U][NV];
+            float wu[U];
 #pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                const int c0 = (k * LPR + l) * 4;
-                if (c0 < a.D) fma4(acc[k], w, ld4(p + c0));
+            for (int u = 0; u < U; ++u) {
+                const int j = min(j0 + u, steps - 1);
+                int c; float w;
+                if constexpr (G == 1) {
+                    c = __builtin_amdgcn_readlane(c_cur, j);
+                    w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, w_cur), j));
+                } else {
+                    c = __shfl(c_cur, j * G + sub, 64);
+                    w = __shfl(w_cur, j * G + sub, 64);
+                }
+                wu[u] = j0 + u < steps ? w : 0.f;
+                const TIn* p = src + (size_t)c * a.ld_src;
+#pragma unroll
+                for (int k = 0; k < NV; ++k) {
+                    const int c0 = (k * LPR + l) * 4;
+                    x[u][k] = c0 < a.D ? ld4(p + c0) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int k = 0; k < NV; ++k) fma4(acc[k], wu[u], x[u][k]);
         }
         c_cur = c_nxt; w_cur = w_nxt;
     }
