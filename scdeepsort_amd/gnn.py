@@ -67,11 +67,12 @@ class GNN(nn.Module):
     # -- one NodeFlow block, both node types ------------------------------------------------------
     def _pad_width(self, g: CellGeneGraph, H: int) -> int:
         """Large graphs run the LDS-streamed kernel, whose hand-scheduled D = 256 specialisation is ~2x faster per
-        edge than the generic one: a hidden width in (192, 256) - e.g. the reference default hidden_dim = 200,
-        train.py:137 - is carried as 256 columns with zero weights / bias in the padding (exact: the extra columns stay 0
-        through ReLU and meet zero weight columns in the next layer)."""
+        edge than the generic one at ANY narrower width (measured at cfg3: 2.6-2.8 ms for D = 64..200 vs 1.3 ms at
+        D = 256).  A narrower hidden width - e.g. the reference default hidden_dim = 200, train.py:137 - is therefore
+        carried as 256 columns with zero weights / bias in the padding (exact: the extra columns stay 0 through ReLU
+        and meet zero weight columns in the next layer)."""
         from . import ops
-        if 192 < H < 256 and ops.TILED_MIN_WORK is not None and g.cg.nnz * 256 >= ops.TILED_MIN_WORK:
+        if H < 256 and ops.TILED_MIN_WORK is not None and g.cg.nnz * 256 >= ops.TILED_MIN_WORK:
             return 256
         return H
 
@@ -79,14 +80,14 @@ class GNN(nn.Module):
                want_genes: bool, cell_rows: Optional[torch.Tensor]):
         G = self.gene_num
         W, b = layer.fc_neigh.weight, layer.fc_neigh.bias
+        project_first = self.order == "project_first" or (self.order == "auto" and W.shape[0] <= W.shape[1])
         if h_g.shape[1] > W.shape[1]:                      # input carried padded (see _pad_width): zero weight columns
             W = F.pad(W, (0, h_g.shape[1] - W.shape[1]))
-        Hp = self._pad_width(g, W.shape[0])
+        Hp = self._pad_width(g, W.shape[0]) if project_first else W.shape[0]
         if Hp != W.shape[0] and layer.norm is None:
             W, b = F.pad(W, (0, 0, 0, Hp - W.shape[0])), F.pad(b, (0, Hp - b.shape[0]))
         act = layer.activation
         fuse_relu = _is_relu(act)
-        project_first = self.order == "project_first" or (self.order == "auto" and W.shape[0] <= W.shape[1])
         if self.dropout is not None:                       # node rows, before the gather (gnn.py:62-64)
             h_g, h_c = self.dropout(h_g), self.dropout(h_c)
         if h_g.dtype != W.dtype:                           # fp16-stored features (BASELINE cfg5): widened on the way

@@ -570,23 +570,24 @@ def test_fp16_stored_features_match_oracle_on_rounded_inputs():
         np.testing.assert_allclose(got, want, atol=TOL, err_msg=order)
 
 
-def test_hidden_200_is_carried_as_256_columns_on_the_tiled_path():
+@pytest.mark.parametrize("hidden", [200, 64])
+def test_narrow_hidden_is_carried_as_256_columns_on_the_tiled_path(hidden):
     """Reference default hidden_dim = 200 (train.py:137): on graphs big enough for the LDS-streamed kernel the hidden
     width is zero-padded to 256 so the D = 256 specialisation runs; logits and gradients are unchanged."""
     from scdeepsort_amd import ops
-    c = small_case(cells=300, genes=180, dim=260, hidden=200, n_classes=6, seed=51, test_cells=0)
+    c = small_case(cells=300, genes=180, dim=260, hidden=hidden, n_classes=6, seed=51, test_cells=0)
     G = c["G"]
-    sd = O.init_params(260, 200, 6, 2, G, seed=12)
+    sd = O.init_params(260, hidden, 6, 2, G, seed=12)
     rg = O.build_reference_graph(c["expr"])
     seeds = np.arange(G, G + c["C"])
     labels = torch.from_numpy(np.random.default_rng(3).integers(0, 6, c["C"]))
     loss_ref, grads_ref, logits_ref = O.loss_and_grads(sd, rg, torch.from_numpy(c["feats"]), seeds, labels, 2)
     g = sda.CellGeneGraph.from_expression(c["expr"], device=DEV)
-    m = make_model(sd, 260, 200, 6, 2, G)
+    m = make_model(sd, 260, hidden, 6, 2, G)
     saved = ops.TILED_MIN_WORK
     ops.TILED_MIN_WORK = 1
     try:
-        assert m._pad_width(g, 200) == 256
+        assert m._pad_width(g, hidden) == 256
         ops.PROFILE = []
         logits = m(g, dev(c["feats"]))
         kernels = {dict(zip(t[::2], t[1::2]))["kernel"] for t, _, _ in ops.PROFILE}
@@ -602,4 +603,4 @@ def test_hidden_200_is_carried_as_256_columns_on_the_tiled_path():
     for n, p in m.named_parameters():
         ref = grads_ref[n].numpy()
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=TOL * max(1.0, float(np.abs(ref).max())), err_msg=n)
-    assert m.embed(g, dev(c["feats"])).shape[1] == 200
+    assert m.embed(g, dev(c["feats"])).shape[1] == hidden
