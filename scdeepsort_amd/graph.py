@@ -33,6 +33,16 @@ from . import _lib
 DEFAULT_CHUNK = 2048
 
 
+def auto_chunk(nnz: int) -> int:
+    """Row-chunk length of the row-wave kernels: short enough that the ~8k resident wavefronts of the chip all get
+    work and the longest item does not dominate (cfg2: 256 is 2x faster than 2048), long enough that the partial-sum
+    traffic stays small on big graphs.  Power of two in [256, 2048]."""
+    c = 256
+    while c < 2048 and c * 8192 < nnz:
+        c *= 2
+    return c
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -58,11 +68,17 @@ class Plan:
         return self.long_rows.shape[0]
 
 
-def build_plan(rowptr_host: np.ndarray, chunk: int = DEFAULT_CHUNK, row_ids_host: Optional[np.ndarray] = None,
+def build_plan(rowptr_host: np.ndarray, chunk: Optional[int] = None, row_ids_host: Optional[np.ndarray] = None,
                device: torch.device | str = "cpu") -> Plan:
-    """Host-side plan construction through the C ABI (``wgnn_plan_build_host``)."""
+    """Host-side plan construction through the C ABI (``wgnn_plan_build_host``); ``chunk=None`` -> ``auto_chunk``."""
     lib = _lib.lib()
     rowptr_host = np.ascontiguousarray(rowptr_host, dtype=np.int32)
+    if chunk is None:
+        if row_ids_host is not None:
+            ids = np.asarray(row_ids_host, dtype=np.int64)
+            chunk = auto_chunk(int((rowptr_host[ids + 1] - rowptr_host[ids]).sum()) if len(ids) else 0)
+        else:
+            chunk = auto_chunk(int(rowptr_host[-1]) if len(rowptr_host) else 0)
     n_rows = len(row_ids_host) if row_ids_host is not None else len(rowptr_host) - 1
     rid = None
     if row_ids_host is not None:
@@ -133,7 +149,7 @@ class AggCsr:
         """Plan restricted to a seed subset (one NodeFlow batch, train.py:71-81).  Not cached: the id
         tensor's storage may be recycled with other contents between calls."""
         ids32 = row_ids.to(torch.int32).contiguous()
-        plan = build_plan(self.rowptr_host, self.plan.chunk, ids32.cpu().numpy(), device=self.device)
+        plan = build_plan(self.rowptr_host, None, ids32.cpu().numpy(), device=self.device)
         return ids32.to(self.device), plan
 
 
@@ -150,7 +166,7 @@ def _normalize_on_device(rowptr: torch.Tensor, raw: torch.Tensor) -> Tuple[torch
 
 
 def _make_csr(rowptr_host: np.ndarray, col_host: np.ndarray, raw_host: np.ndarray, n_rows: int, n_cols: int,
-              device: torch.device, chunk: int) -> AggCsr:
+              device: torch.device, chunk: Optional[int]) -> AggCsr:
     if rowptr_host[-1] >= 2 ** 31:
         raise ValueError("nnz >= 2^31: shard the cell axis (CellGeneGraph.shard)")
     rowptr = torch.from_numpy(np.ascontiguousarray(rowptr_host, dtype=np.int32)).to(device)
@@ -180,7 +196,7 @@ class CellGeneGraph:
 
     @staticmethod
     def from_expression(expr, support_mask: Optional[np.ndarray] = None, device: torch.device | str = "cuda",
-                        chunk: int = DEFAULT_CHUNK) -> "CellGeneGraph":
+                        chunk: Optional[int] = None) -> "CellGeneGraph":
         """Build from a scipy (cells x genes) matrix of raw expression values (entries > threshold only).
 
         Mirrors the reference build order: both edge directions from the same raw value
@@ -204,7 +220,7 @@ class CellGeneGraph:
 
     @staticmethod
     def from_device_csr(rowptr: torch.Tensor, col: torch.Tensor, raw: torch.Tensor, num_genes: int,
-                        chunk: int = DEFAULT_CHUNK) -> "CellGeneGraph":
+                        chunk: Optional[int] = None) -> "CellGeneGraph":
         """Build from a device CSR of the (cells x genes) raw expression (all cells are support cells)."""
         dev = col.device
         C_ = rowptr.shape[0] - 1
@@ -231,7 +247,7 @@ class CellGeneGraph:
 
     @staticmethod
     def cell_features(rowptr: torch.Tensor, col: torch.Tensor, raw: torch.Tensor, gene_feat: torch.Tensor,
-                      chunk: int = DEFAULT_CHUNK) -> torch.Tensor:
+                      chunk: Optional[int] = None) -> torch.Tensor:
         """``cell_feat = rownorm(X) . gene_feat`` with ``rownorm(X)[c,g] = x/(sum_g x + 1e-6)``
         (preprocess_internal.py:197-199, preprocess.py:205-207) as the same weighted SpMM the hot path uses (K1,
         NO_ALPHA, no mean, no self-loop) instead of the reference's dense (cells x genes) matrix product."""

@@ -6,13 +6,15 @@ With ``world_size == 1`` it degenerates to the plain single-GPU ``GNN.forward``.
 """
 from __future__ import annotations
 
+from typing import Optional
+
 import torch
 import torch.nn.functional as F
 
 from . import dist as D
 from ._lib import NO_ALPHA, SRC_IS_GENE
 from .gnn import GNN
-from .graph import AggCsr, CellGeneGraph, _normalize_on_device, build_plan, DEFAULT_CHUNK
+from .graph import AggCsr, CellGeneGraph, _normalize_on_device, build_plan
 from .ops import agg_fwd, weighted_mean_aggregate, weighted_sum
 
 
@@ -35,7 +37,7 @@ class ShardedWgnn:
 
     @staticmethod
     def build(model: GNN, rowptr: torch.Tensor, col: torch.Tensor, raw: torch.Tensor, num_genes: int,
-              chunk: int = DEFAULT_CHUNK, global_stats=None) -> "ShardedWgnn":
+              chunk: Optional[int] = None, global_stats=None) -> "ShardedWgnn":
         """``rowptr/col/raw``: device CSR of THIS rank's (cells x genes) raw expression.
         ``global_stats`` = (deg, sum) over ALL shards; when None and a process group is up they are all-reduced."""
         rank, world = D.world()
