@@ -124,3 +124,32 @@ def test_neighbour_sampler_is_uniform_and_seeded():
     a = sample_block(csr, rows, 5, torch.Generator().manual_seed(5))
     b = sample_block(csr, rows, 5, torch.Generator().manual_seed(5))
     assert torch.equal(a.csr.col, b.csr.col) and torch.equal(a.self_drawn, b.self_drawn)
+
+
+def test_generated_flat_pipeline_is_in_sync_and_well_formed(tmp_path):
+    """csrc/wgnn_flat_asm.inc is generated (gen_flat_asm.py): the committed file must be the generator's output, every
+    step must keep its LDS wait count consistent with the reads issued after the pair it consumes, and every branch
+    target must exist."""
+    import re
+    import runpy
+    from pathlib import Path
+    csrc = Path(sda.__file__).resolve().parent / "csrc"
+    gen = runpy.run_path(str(csrc / "gen_flat_asm.py"))
+    out = tmp_path / "flat.inc"
+    gen["main"](str(out))
+    assert out.read_text() == (csrc / "wgnn_flat_asm.inc").read_text()
+    lines = [l.strip().strip('"\\ ').replace("\\n\\t", "") for l in out.read_text().splitlines() if l.strip().startswith('"')]
+    labels = {l[:-1] for l in lines if l.endswith(":")}
+    for l in lines:
+        m = re.match(r"s_branch (\S+)", l)
+        if m:
+            assert m.group(1) in labels, l
+    assert sum(1 for l in labels if "_step" in l) == 32 and sum(1 for l in labels if "_pre" in l) == 32
+    # per step: reads of pair p+1 (3 LDS ops) are outstanding when pair p is consumed
+    text = "\n".join(lines)
+    for p in range(32):
+        body = text.split(f".Lw4_step{p}_%=:")[1].split(".Lw4_step")[0]
+        n_reads = len(re.findall(r"ds_read_b(128|64)", body))
+        wait = int(re.search(r"s_waitcnt lgkmcnt\((\d+)\)", body).group(1))
+        assert n_reads == (3 if p < 31 else 0) and wait == n_reads, (p, n_reads, wait)
+        assert len(re.findall(r"v_pk_fma_f32", body)) == 4
