@@ -323,17 +323,14 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
         if (do_fill) fill(0);
         chunk_issue(S0{}, sA, eA);
         if (nblk > 1) chunk_issue(S1{}, sB, eB);
-        int b = 0;
-        for (; b + 8 < nblk; b += 6) {                       // six blocks per trip (the last one prefetches up to block b+8):
-                                                             // register sets (x3) and buffer parity (x2) rotate statically
-            fast_block(S0{}, S2{}, 0, sA, eA, sC, eC);
-            fast_block(S1{}, S0{}, 1, sB, eB, sA, eA);
-            fast_block(S2{}, S1{}, 0, sC, eC, sB, eB);
-            fast_block(S0{}, S2{}, 1, sA, eA, sC, eC);
-            fast_block(S1{}, S0{}, 0, sB, eB, sA, eA);
-            fast_block(S2{}, S1{}, 1, sC, eC, sB, eB);
+        int b = 0, par = 0;
+        for (; b + 5 < nblk; b += 3) {                       // three blocks per trip (the last one prefetches up to block b+5):
+            fast_block(S0{}, S2{}, par, sA, eA, sC, eC);     // the register sets rotate statically, the buffer parity
+            fast_block(S1{}, S0{}, par ^ 1, sB, eB, sA, eA); // is a scalar
+            fast_block(S2{}, S1{}, par, sC, eC, sB, eB);
+            par ^= 1;
         }
-        for (; b < nblk; b += 3) {                           // the last 3..11 blocks: general form
+        for (; b < nblk; b += 3) {                           // the last 3..8 blocks: general form
             block(S0{}, S2{}, b, sA, eA, sC, eC);
             if (b + 1 < nblk) block(S1{}, S0{}, b + 1, sB, eB, sA, eA);
             if (b + 2 < nblk) block(S2{}, S1{}, b + 2, sC, eC, sB, eB);
