@@ -8,6 +8,8 @@ point depends on m.  Per pair the pipeline is
     step p-2 : v_readlane pk of pair p -> SGPR set p%3 ; v_and_or -> LDS addresses of pair p
     step p-1 : ds_read_b128 x2 of pair p -> staging buffer X[p%2] ; ds_read_b64 (broadcast) of its two weights -> W[p%2]
     step p   : s_waitcnt ; 4 x v_pk_fma_f32 into the GPR-indexed accumulators
+Within a step the order is R(eads of p+1) L(readlanes of p+2) A(ddresses of p+2) W(ait) F(mas of p): the address VALU
+work sits in the shadow of the LDS wait (measured 2-3 % faster than addresses after the FMAs).
 
 (the kernel is VALU-issue bound - 4 VALU per entry: 1 readlane, 1 address, 2 FMA - so the weights come through an LDS
 broadcast read of the wave's 256-byte weight strip instead of a second v_readlane)
@@ -51,6 +53,7 @@ def wreg(p):
 
 WRL = "wrl" in ABLATE            # experiment: weights through v_readlane into SGPR pairs instead of the LDS strip
 SCR = 92                         # scratch SGPR of the computed branch
+ORDER = os.environ.get("WGNN_GEN_ORDER", "RLAWF")     # order of a step's groups: R(eads) L(readlanes) W(ait) F(mas) A(ddresses)
 
 
 def wsgpr(p):
@@ -119,16 +122,19 @@ def fmas(p):
 def step(p):
     """Steady-state step p: fetch pair p+DEPTH, prepare pair p+DEPTH+1, accumulate pair p."""
     out = [f".Lw4_step{p}_%=:"]
-    if p + DEPTH < N_PAIRS:
-        out += reads(p + DEPTH)
-    if p + DEPTH + 1 < N_PAIRS:
-        out += readlanes(p + DEPTH + 1)
-    if "nords" not in ABLATE:
-        ahead = min(DEPTH, N_PAIRS - 1 - p)           # pairs fetched after pair p
-        out.append(f"s_waitcnt lgkmcnt({(2 if WRL else 3) * ahead})")
-    out += fmas(p)
-    if p + DEPTH + 1 < N_PAIRS:
-        out += addresses(p + DEPTH + 1)
+    R = reads(p + DEPTH) if p + DEPTH < N_PAIRS else []
+    L = readlanes(p + DEPTH + 1) if p + DEPTH + 1 < N_PAIRS else []
+    A = addresses(p + DEPTH + 1) if p + DEPTH + 1 < N_PAIRS else []
+    ahead = min(DEPTH, N_PAIRS - 1 - p)               # pairs fetched after pair p
+    W = [] if "nords" in ABLATE else [f"s_waitcnt lgkmcnt({(2 if WRL else 3) * ahead})"]
+    F = fmas(p)
+    parts = dict(R=R, L=L, A=A, W=W, F=F)
+    if ORDER == "interleave":                         # FMAs of the two entries around the scalar work
+        f0, f1 = F[:3], F[3:]
+        out += R + L[:1] + W + f0 + L[1:] + f1 + A
+    else:
+        for k in ORDER:
+            out += parts[k]
     if "xrl" in ABLATE:
         out += ["v_readlane_b32 s86, %[pk], 3", "v_readlane_b32 s86, %[pk], 5"]
     if "xvmov" in ABLATE:
