@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from . import dist as D
-from ._lib import NO_ALPHA, SRC_IS_GENE
+from ._lib import DST_IS_GENE, NO_ALPHA, SRC_IS_GENE
 from .gnn import GNN
 from .graph import AggCsr, CellGeneGraph, _normalize_on_device, build_plan
 from .ops import agg_fwd, weighted_mean_aggregate, weighted_sum
@@ -81,10 +81,23 @@ class ShardedWgnn:
 
         def genes_finish(part, p_g, b, relu):
             a = m.alpha.reshape(-1)
+            if not (torch.is_grad_enabled() and (part.requires_grad or p_g.requires_grad or a.requires_grad)):
+                # one K1 launch over an identity CSR: (alpha[r]*1*part[r] + alpha[G]*p_g[r]) * inv_deg[r] + b, ReLU fused
+                return agg_fwd(self._identity(), a, DST_IS_GENE, G, part, p_g, bias=b, relu=relu)
             z = (a[:G].unsqueeze(1) * part + a[G] * p_g) * g.gc.inv_deg.unsqueeze(1) + b
             return F.relu(z) if relu else z
 
         return D.LocalOps(cells_layer, genes_partial, genes_finish)
+
+    def _identity(self) -> AggCsr:
+        """G x G identity CSR carrying the GLOBAL gene-side 1/(deg+1): lets K1's epilogue finish the all-reduced sums."""
+        if getattr(self, "_eye", None) is None:
+            G, dev = self.graph.num_genes, self.graph.device
+            rp = torch.arange(G + 1, dtype=torch.int32, device=dev)
+            host = rp.cpu().numpy()
+            self._eye = AggCsr(rp, torch.arange(G, dtype=torch.int32, device=dev), torch.ones(G, device=dev),
+                               self.graph.gc.inv_deg, G, G, build_plan(host, device=dev), host)
+        return self._eye
 
     def _weights(self):
         m = self.model
