@@ -2,7 +2,8 @@
  *
  * Used by tests/ as a second, independent checker and by bench.py as the timed
  * `cpu_baseline` ("port": the reference itself cannot run - DGL 0.4.3 is absent).
- * PARITY UNPINNED (see oracle/wgnn_oracle.py header).
+ * PARITY: pinned against the reference's own Python code executed over a DGL stand-in, UNPINNED against DGL itself
+ * (see oracle/wgnn_oracle.py header).
  *
  * Follows the reference's arithmetic order:
  *   message   m_e = (h[src] * alpha[k(e)]) * w_e                 models/gnn.py:54,56

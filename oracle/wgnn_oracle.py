@@ -4,14 +4,18 @@ TEST INFRASTRUCTURE ONLY.  Nothing under ``scdeepsort_amd/`` imports this file;
 only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 leg may use it, and only as the checker.
 
-PARITY UNPINNED: the reference ships no tests, golden vectors or checkpoints
-for this path and its arithmetic lives in DGL 0.4.3.post2 (requirements.txt:5),
-which is neither vendored under /root/reference nor installable here, so no
-reference code can execute.  This restatement follows the reference source
-line by line (citations below) plus DGL 0.4.x's documented semantics for
-``fn.mean`` / ``NodeFlow.block_compute``; it is pinned only by hand-derived
-known answers (tests/golden/kat_*.json), by agreement of two independent
-formulations (edge-list vs CSR) and by algebraic properties.
+PARITY STATUS - pinned against the reference's own Python code, UNPINNED against DGL.  The reference ships no tests,
+golden vectors or checkpoints for this path, and the reduce / NodeFlow part of its arithmetic lives in DGL 0.4.3.post2
+(requirements.txt:5), which is neither vendored under /root/reference nor installable here.  What could be done, and
+is: the reference's OWN code for the path - ``GNN.forward`` / ``message_func`` / ``NodeUpdate`` (models/gnn.py:10-68)
+and ``normalize_weight`` (utils/preprocess_internal.py:15-23) - was imported from /root/reference in the build
+container and EXECUTED over a ~70-line stand-in for the DGL objects it touches (NodeFlow frames + ``block_compute`` +
+``fn.mean`` with their documented semantics); the resulting logits and normalised edge weights are committed as
+``tests/golden/refcode_*.npz`` (script: ``tests/golden/make_refcode_golden.py``) and both formulations below reproduce
+them to 2e-6.  What stays restated-from-documentation is DGL's side: ``fn.mean`` = sum over in-edges / in-degree, a
+NodeFlow block = all parent in-edges when expand_factor >= degree, ``edata[...]`` writes through.  Further pins:
+hand-derived known answers (tests/golden/kat_*.json), agreement of two independent formulations (edge-list vs CSR),
+algebraic properties, finite-difference gradients.
 
 Two formulations live here:
 

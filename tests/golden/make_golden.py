@@ -7,8 +7,8 @@ Outputs (tests/golden/):
   kat_2x2.json          hand-derived known answer - written by hand below, NOT computed
   testis199.npz         expression CSR of mouse_Testis199 (199 cells x 9339 genes, 75,168 nnz) + oracle outputs
   pancreas11.npz        expression CSR of human_Pancreas11 (11 cells x 2650 genes, dense)   + oracle outputs
-The reference cannot execute here (DGL 0.4.3 absent), so these vectors pin the
-restatement against itself over time, not against the reference: PARITY UNPINNED.
+DGL 0.4.3 is absent, so THESE vectors pin the restatement against itself over time; the
+fixtures that come from executing the reference's own code are made by make_refcode_golden.py.
 """
 import json
 import sys

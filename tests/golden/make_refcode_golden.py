@@ -1,0 +1,177 @@
+"""Golden vectors produced by EXECUTING THE REFERENCE'S OWN CODE for the hot path - run in the BUILD container only:
+
+    python tests/golden/make_refcode_golden.py        ->  tests/golden/refcode_{train,predict}.npz
+
+What runs verbatim from /root/reference (imported at generation time, never copied, never shipped):
+  * models/gnn.py        : GNN.__init__, GNN.message_func (alpha-index cascade, multiply order), GNN.forward,
+                           NodeUpdate.forward                                   (gnn.py:10-68)
+  * utils/preprocess_internal.py : normalize_weight                             (preprocess_internal.py:15-23)
+
+What does NOT run: DGL 0.4.3.post2 itself (absent from the image, not installable).  The reference code above only
+touches DGL through `graph.in_degrees / in_edges / edata / number_of_nodes`, `nf.layers[i].data`, `nf.block_compute`
+and `fn.mean`; those are provided here by a ~70-line STAND-IN that implements their documented semantics:
+  - fn.mean('m','neigh'): neigh[v] = sum of the messages on v's in-edges / number of those edges;
+  - NodeFlow with expand_factor >= every in-degree: block i holds ALL parent in-edges of layer i+1's nodes,
+    layer i = the sources of those edges (train.py:37-38,71-78);
+  - `graph.edata['weight'][ids] = x` writes through (the reference relies on it).
+So these fixtures pin the repo's restatement of the REFERENCE'S OWN arithmetic (alpha indexing, (h*alpha)*w order,
+normalise-then-self-loop, Linear+ReLU, head) against that code as executed; the DGL-internal part of the path stays
+restated-from-documentation, which is why the oracle header keeps saying PARITY UNPINNED.
+"""
+import importlib.util
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REF = Path("/root/reference")
+HERE = Path(__file__).resolve().parent
+
+
+# ------------------------------------------------------------------------------------------------ DGL stand-in
+def install_dgl_standin():
+    dgl = types.ModuleType("dgl")
+    fn = types.ModuleType("dgl.function")
+    fn.mean = lambda msg, out: ("mean", msg, out)
+    dgl.function = fn
+    for name in ("DGLGraph", "NodeFlow", "EdgeBatch"):
+        setattr(dgl, name, type(name, (), {}))
+    sys.modules["dgl"], sys.modules["dgl.function"] = dgl, fn
+
+
+class GraphStandIn:
+    """The slice of DGLGraph that normalize_weight touches; edges in insertion order."""
+
+    def __init__(self, n_nodes, src, dst, weight):
+        self.n, self.src, self.dst = n_nodes, torch.as_tensor(src), torch.as_tensor(dst)
+        self.edata = {"weight": torch.as_tensor(weight, dtype=torch.float32).clone().unsqueeze(-1)}
+
+    def number_of_nodes(self):
+        return self.n
+
+    def in_degrees(self):
+        return torch.bincount(self.dst, minlength=self.n)
+
+    def in_edges(self, v, form="all"):
+        eid = torch.nonzero(self.dst == v).squeeze(-1)
+        return self.src[eid], self.dst[eid], eid
+
+
+class _Frame:
+    def __init__(self, data):
+        self.data = data
+
+
+class _Batch:
+    def __init__(self, src, dst, data):
+        self.src, self.dst, self.data = src, dst, data
+
+
+class NodeFlowStandIn:
+    """Full-neighbourhood NodeFlow of `seeds` over a parent graph given as (src, dst, weight, node_id, features)."""
+
+    def __init__(self, src, dst, weight, node_id, features, seeds, n_layers):
+        layers, blocks = [np.asarray(seeds, dtype=np.int64)], []
+        for _ in range(n_layers):
+            cur = layers[0]
+            pos = {int(v): j for j, v in enumerate(cur)}
+            sel = np.nonzero(np.isin(dst, cur))[0]
+            prev, src_local = np.unique(src[sel], return_inverse=True)
+            blocks.insert(0, (src_local, np.array([pos[int(d)] for d in dst[sel]], dtype=np.int64), weight[sel]))
+            layers.insert(0, prev)
+        self.layer_nids = layers
+        self.layers = [_Frame({"id": torch.from_numpy(node_id[l]).unsqueeze(-1)}) for l in layers]
+        self.layers[0].data["features"] = torch.from_numpy(features[layers[0]])
+        self._blocks = blocks
+
+    def block_compute(self, i, message_func, reduce_func, apply_func):
+        kind, msg, out = reduce_func
+        assert kind == "mean"
+        e_src, e_dst, w = self._blocks[i]
+        s, d = torch.from_numpy(e_src), torch.from_numpy(e_dst)
+        batch = _Batch({k: v[s] for k, v in self.layers[i].data.items()}, {k: v[d] for k, v in self.layers[i + 1].data.items()},
+                       {"weight": torch.from_numpy(w)})
+        m = message_func(batch)[msg]
+        n_dst = len(self.layer_nids[i + 1])
+        total = torch.zeros(n_dst, m.shape[1], dtype=m.dtype).index_add_(0, d, m)
+        deg = torch.zeros(n_dst, dtype=m.dtype).index_add_(0, d, torch.ones(len(d), dtype=m.dtype))
+        self.layers[i + 1].data[out] = total / deg.unsqueeze(-1)
+        self.layers[i + 1].data.update(apply_func(self.layers[i + 1]))
+
+
+def load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+# ------------------------------------------------------------------------------------------------ cases
+def build_edges(expr, support_mask):
+    """Node order and edge set of the reference graph (preprocess_internal.py:107-110,160-173; predict graphs:
+    preprocess.py:126-134,184-187): genes 0..G-1 (id = index), cells after them (id = -1); every stored entry gives a
+    gene->cell edge, support cells also the cell->gene edge; raw weight = expression value on both."""
+    C, G = expr.shape
+    r, c = np.nonzero(expr)
+    w = expr[r, c].astype(np.float32)
+    sup = support_mask[r]
+    src = np.concatenate([r[sup] + G, c]); dst = np.concatenate([c[sup], r + G]); wt = np.concatenate([w[sup], w])
+    node_id = np.concatenate([np.arange(G), -np.ones(C)]).astype(np.int32)
+    return src.astype(np.int64), dst.astype(np.int64), wt, node_id
+
+
+def make_case(name, gnn_mod, pre_mod, expr, support_mask, dim, hidden, n_classes, n_layers, seed):
+    C, G = expr.shape
+    N = G + C
+    src, dst, raw, node_id = build_edges(expr, support_mask)
+    graph = GraphStandIn(N, src, dst, raw)
+    pre_mod.normalize_weight(graph)                                           # REFERENCE CODE
+    w_norm = graph.edata["weight"].squeeze(-1).numpy().copy()
+    # self-loops AFTER normalisation, weight 1 (preprocess_internal.py:211-214)
+    loops = np.arange(N)
+    src2, dst2 = np.concatenate([src, loops]), np.concatenate([dst, loops])
+    w2 = np.concatenate([w_norm, np.ones(N, np.float32)]).astype(np.float32)[:, None]
+    torch.manual_seed(seed)
+    model = gnn_mod.GNN(dim, hidden, n_classes, n_layers, G, activation=torch.nn.functional.relu)   # REFERENCE CODE
+    with torch.no_grad():
+        model.alpha.uniform_(0.5, 1.5)
+        for p in model.parameters():
+            if p.dim() == 1:
+                p.uniform_(-0.3, 0.3)
+    model.eval()
+    rng = np.random.default_rng(seed)
+    feats = (0.5 * rng.standard_normal((N, dim))).astype(np.float32)
+    seeds = np.arange(G, N)
+    nf = NodeFlowStandIn(src2, dst2, w2, node_id, feats, seeds, n_layers)
+    with torch.no_grad():
+        logits = model(nf).numpy()                                            # REFERENCE CODE (GNN.forward)
+    out = dict(expr=expr.astype(np.float32), support_mask=support_mask, dim=dim, hidden=hidden, n_classes=n_classes,
+               n_layers=n_layers, feats=feats, seeds=seeds, logits=logits,
+               edge_src=src, edge_dst=dst, edge_w_raw=raw, edge_w_norm=w_norm)
+    for k, v in model.state_dict().items():
+        out["param." + k] = v.numpy()
+    np.savez_compressed(HERE / f"{name}.npz", **out)
+    print(f"{name}: {C} cells x {G} genes, {len(src)} edges, logits {logits.shape}, |logits|max {np.abs(logits).max():.3f}")
+
+
+def main():
+    install_dgl_standin()
+    gnn_mod = load(REF / "models" / "gnn.py", "ref_gnn")
+    pre_mod = load(REF / "utils" / "preprocess_internal.py", "ref_preprocess_internal")
+    rng = np.random.default_rng(2024)
+    for name, C, G, test_cells, L in (("refcode_train", 14, 9, 0, 2), ("refcode_predict", 17, 11, 5, 2), ("refcode_1layer", 10, 7, 3, 1)):
+        mask = rng.random((C, G)) < 0.35
+        mask[:, 0] = True                 # a hub gene
+        mask[2, :] = False                # a cell expressing nothing
+        mask[:, G - 1] = False            # a gene no cell expresses
+        expr = np.where(mask, np.clip(rng.normal(3.0, 0.9, (C, G)), 0.5, 7.0), 0.0).astype(np.float32)
+        support = np.ones(C, bool)
+        if test_cells:
+            support[-test_cells:] = False
+        make_case(name, gnn_mod, pre_mod, expr, support, dim=12, hidden=8, n_classes=4, n_layers=L, seed=C * 100 + G)
+
+
+if __name__ == "__main__":
+    main()

@@ -604,3 +604,28 @@ def test_narrow_hidden_is_carried_as_256_columns_on_the_tiled_path(hidden):
         ref = grads_ref[n].numpy()
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=TOL * max(1.0, float(np.abs(ref).max())), err_msg=n)
     assert m.embed(g, dev(c["feats"])).shape[1] == hidden
+
+
+@pytest.mark.parametrize("name", ["refcode_train", "refcode_predict", "refcode_1layer"])
+@pytest.mark.parametrize("order", ["project_first", "aggregate_first"])
+def test_hip_path_matches_executed_reference_code(name, order):
+    """The fixtures hold logits computed by the reference's OWN gnn.py + normalize_weight, executed over a stand-in for
+    DGL's NodeFlow / fn.mean (tests/golden/make_refcode_golden.py): the HIP path must reproduce them."""
+    z = np.load(GOLDEN / f"{name}.npz")
+    sd = {k[len("param."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param.")}
+    expr = sp.csr_matrix(z["expr"]); G = expr.shape[1]
+    g = sda.CellGeneGraph.from_expression(expr, z["support_mask"], device=DEV)
+    m = make_model(sd, int(z["dim"]), int(z["hidden"]), int(z["n_classes"]), int(z["n_layers"]), G, order)
+    with torch.no_grad():
+        got = m(g, dev(z["feats"]), seeds=torch.from_numpy(z["seeds"]).to(DEV)).cpu().numpy()
+    np.testing.assert_allclose(got, z["logits"], atol=TOL)
+    # the device normalisation (K4) against the executed normalize_weight
+    want = {(int(s), int(d)): float(w) for s, d, w in zip(z["edge_src"], z["edge_dst"], z["edge_w_norm"])}
+    rp, col, val = g.cg.rowptr.cpu().numpy(), g.cg.col.cpu().numpy(), g.cg.val.cpu().numpy()
+    for c in range(expr.shape[0]):
+        for j in range(rp[c], rp[c + 1]):
+            assert abs(val[j] - want[(int(col[j]), G + c)]) < 2e-6            # gene -> cell
+    rp, col, val = g.gc.rowptr.cpu().numpy(), g.gc.col.cpu().numpy(), g.gc.val.cpu().numpy()
+    for gi in range(G):
+        for j in range(rp[gi], rp[gi + 1]):
+            assert abs(val[j] - want[(G + int(col[j]), gi)]) < 2e-6            # cell -> gene

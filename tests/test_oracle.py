@@ -1,6 +1,6 @@
 """CPU tests of the oracle itself: known answers, dual-formulation agreement, algebraic
-properties.  The reference holds no test vectors for this path
-(parity unpinned), so these are what pin the restatement."""
+properties, and fixtures made by EXECUTING the reference's own gnn.py / normalize_weight over a
+stand-in for DGL (tests/golden/make_refcode_golden.py).  The reference holds no test vectors of its own for this path."""
 import json
 
 import numpy as np
@@ -168,3 +168,32 @@ def test_sampled_nodeflow_replay_matches_rng_draw():
     b = O.nodeflow_forward(sd, rg, x, seeds, 2, picker=lambda blk, v: rec[(blk, v)])
     assert torch.equal(a, b)
     assert not torch.allclose(a, full)
+
+
+# ---- fixtures produced by executing the reference's own gnn.py / normalize_weight (tests/golden/make_refcode_golden.py)
+def _load_refcode(name):
+    z = np.load(GOLDEN / f"{name}.npz")
+    sd = {k[len("param."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param.")}
+    return z, sd
+
+
+@pytest.mark.parametrize("name", ["refcode_train", "refcode_predict", "refcode_1layer"])
+def test_restatement_matches_executed_reference_code(name):
+    """GNN.forward / message_func / NodeUpdate (gnn.py:10-68) and normalize_weight (preprocess_internal.py:15-23) were
+    EXECUTED from the reference tree over a stand-in for DGL's NodeFlow / fn.mean; both formulations of the oracle must
+    reproduce those logits and those normalised edge weights."""
+    z, sd = _load_refcode(name)
+    expr = sp.csr_matrix(z["expr"]); mask = z["support_mask"]; L = int(z["n_layers"])
+    G = expr.shape[1]
+    rg = O.build_reference_graph(expr, mask)
+    # normalised weights, edge by edge (the oracle's edge order: cell->gene edges of support cells, then gene->cell)
+    got_w = {(int(s), int(d)): float(w) for s, d, w in zip(rg.src, rg.dst, rg.weight) if s != d}
+    want_w = {(int(s), int(d)): float(w) for s, d, w in zip(z["edge_src"], z["edge_dst"], z["edge_w_norm"])}
+    assert got_w.keys() == want_w.keys()
+    assert max(abs(got_w[k] - want_w[k]) for k in want_w) < 2e-6
+    feats = torch.from_numpy(z["feats"])
+    logits_edge = O.nodeflow_forward(sd, rg, feats, z["seeds"], L).numpy()
+    np.testing.assert_allclose(logits_edge, z["logits"], atol=2e-6)
+    cg = O.build_csr_graph(expr, mask)
+    logits_csr = O.csr_forward(sd, cg, z["feats"], L)
+    np.testing.assert_allclose(logits_csr, z["logits"], atol=2e-6)
