@@ -1,6 +1,6 @@
 """Golden vectors produced by EXECUTING THE REFERENCE'S OWN CODE for the hot path - run in the BUILD container only:
 
-    python tests/golden/make_refcode_golden.py        ->  tests/golden/refcode_{train,predict}.npz
+    python tests/golden/make_refcode_golden.py        ->  tests/golden/refcode_{train,predict,1layer}.npz
 
 What runs verbatim from /root/reference (imported at generation time, never copied, never shipped):
   * models/gnn.py        : GNN.__init__, GNN.message_func (alpha-index cascade, multiply order), GNN.forward,
@@ -16,7 +16,9 @@ and `fn.mean`; those are provided here by a ~70-line STAND-IN that implements th
   - `graph.edata['weight'][ids] = x` writes through (the reference relies on it).
 So these fixtures pin the repo's restatement of the REFERENCE'S OWN arithmetic (alpha indexing, (h*alpha)*w order,
 normalise-then-self-loop, Linear+ReLU, head) against that code as executed; the DGL-internal part of the path stays
-restated-from-documentation, which is why the oracle header keeps saying PARITY UNPINNED.
+restated-from-documentation, which is why the oracle header says "pinned against the reference's own Python code,
+UNPINNED against DGL".  Also stored: the loss and autograd gradients of one seed batch through the same code
+(CrossEntropyLoss(reduction='sum'), train.py:34-36,80-84).
 """
 import importlib.util
 import sys
@@ -147,9 +149,19 @@ def make_case(name, gnn_mod, pre_mod, expr, support_mask, dim, hidden, n_classes
     nf = NodeFlowStandIn(src2, dst2, w2, node_id, feats, seeds, n_layers)
     with torch.no_grad():
         logits = model(nf).numpy()                                            # REFERENCE CODE (GNN.forward)
+    # one training step's loss and gradients on a seed batch (train.py:34-36,80-84): CrossEntropyLoss(reduction='sum')
+    batch = seeds[rng.permutation(len(seeds))[: max(3, len(seeds) // 2)]]
+    labels = rng.integers(0, n_classes, len(batch))
+    nfb = NodeFlowStandIn(src2, dst2, w2, node_id, feats, batch, n_layers)
+    loss = torch.nn.CrossEntropyLoss(reduction='sum')(model(nfb), torch.from_numpy(labels))      # REFERENCE CODE + autograd
+    model.zero_grad()
+    loss.backward()
     out = dict(expr=expr.astype(np.float32), support_mask=support_mask, dim=dim, hidden=hidden, n_classes=n_classes,
                n_layers=n_layers, feats=feats, seeds=seeds, logits=logits,
-               edge_src=src, edge_dst=dst, edge_w_raw=raw, edge_w_norm=w_norm)
+               edge_src=src, edge_dst=dst, edge_w_raw=raw, edge_w_norm=w_norm,
+               batch=batch, labels=labels, loss=float(loss))
+    for k, p in model.named_parameters():
+        out["grad." + k] = p.grad.numpy().copy()
     for k, v in model.state_dict().items():
         out["param." + k] = v.numpy()
     np.savez_compressed(HERE / f"{name}.npz", **out)

@@ -629,3 +629,20 @@ def test_hip_path_matches_executed_reference_code(name, order):
     for gi in range(G):
         for j in range(rp[gi], rp[gi + 1]):
             assert abs(val[j] - want[(G + int(col[j]), gi)]) < 2e-6            # cell -> gene
+
+
+@pytest.mark.parametrize("name", ["refcode_train", "refcode_predict", "refcode_1layer"])
+def test_hip_gradients_match_executed_reference_code(name):
+    """K1 forward + K2/K3 backward against the loss and gradients autograd produced through the reference's own code."""
+    z = np.load(GOLDEN / f"{name}.npz")
+    sd = {k[len("param."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param.")}
+    expr = sp.csr_matrix(z["expr"]); G = expr.shape[1]
+    g = sda.CellGeneGraph.from_expression(expr, z["support_mask"], device=DEV)
+    m = make_model(sd, int(z["dim"]), int(z["hidden"]), int(z["n_classes"]), int(z["n_layers"]), G).train()
+    logits = m(g, dev(z["feats"]), seeds=torch.from_numpy(z["batch"]).to(DEV))
+    loss = F.cross_entropy(logits, torch.from_numpy(z["labels"]).to(DEV), reduction="sum")
+    loss.backward()
+    assert abs(float(loss) - float(z["loss"])) < 1e-4 * max(1.0, abs(float(z["loss"])))
+    for k, p in m.named_parameters():
+        ref = z["grad." + k]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=TOL * max(1.0, float(np.abs(ref).max())), err_msg=k)
