@@ -165,18 +165,6 @@ def _normalize_on_device(rowptr: torch.Tensor, raw: torch.Tensor) -> Tuple[torch
     return out, inv_deg
 
 
-def _make_csr(rowptr_host: np.ndarray, col_host: np.ndarray, raw_host: np.ndarray, n_rows: int, n_cols: int,
-              device: torch.device, chunk: Optional[int]) -> AggCsr:
-    if rowptr_host[-1] >= 2 ** 31:
-        raise ValueError("nnz >= 2^31: shard the cell axis (CellGeneGraph.shard)")
-    rowptr = torch.from_numpy(np.ascontiguousarray(rowptr_host, dtype=np.int32)).to(device)
-    col = torch.from_numpy(np.ascontiguousarray(col_host, dtype=np.int32)).to(device)
-    raw = torch.from_numpy(np.ascontiguousarray(raw_host, dtype=np.float32)).to(device)
-    val, inv_deg = _normalize_on_device(rowptr, raw)
-    host = np.ascontiguousarray(rowptr_host, dtype=np.int32)
-    return AggCsr(rowptr, col, val, inv_deg, n_rows, n_cols, build_plan(host, chunk, device=device), host)
-
-
 @dataclass
 class CellGeneGraph:
     num_genes: int
@@ -206,22 +194,20 @@ class CellGeneGraph:
         device = torch.device(device)
         x = sp.csr_matrix(expr).astype(np.float32)
         x.sort_indices()
-        C_, G_ = x.shape
-        if support_mask is None:
-            xs = x
-        else:
-            xs = sp.csr_matrix(sp.diags(np.asarray(support_mask, dtype=np.float32)) @ x)
-            xs.eliminate_zeros()
-        xt = sp.csr_matrix(xs.T)
-        xt.sort_indices()
-        cg = _make_csr(x.indptr, x.indices, x.data, C_, G_, device, chunk)
-        gc = _make_csr(xt.indptr, xt.indices, xt.data, G_, C_, device, chunk)
-        return CellGeneGraph(G_, C_, cg, gc, 0, C_)
+        if x.indptr[-1] >= 2 ** 31:
+            raise ValueError("nnz >= 2^31: shard the cell axis (sharded.ShardedWgnn)")
+        mask = None if support_mask is None else torch.from_numpy(np.asarray(support_mask, dtype=bool)).to(device)
+        # one upload of the CSR; the gene-major copy (transpose), both normalisations and the plans are built on the device
+        return CellGeneGraph.from_device_csr(torch.from_numpy(x.indptr.astype(np.int64)).to(device),
+                                             torch.from_numpy(x.indices.astype(np.int32)).to(device),
+                                             torch.from_numpy(x.data).to(device), x.shape[1], chunk, mask)
 
     @staticmethod
     def from_device_csr(rowptr: torch.Tensor, col: torch.Tensor, raw: torch.Tensor, num_genes: int,
-                        chunk: Optional[int] = None) -> "CellGeneGraph":
-        """Build from a device CSR of the (cells x genes) raw expression (all cells are support cells)."""
+                        chunk: Optional[int] = None, support_mask: Optional[torch.Tensor] = None) -> "CellGeneGraph":
+        """Build from a device CSR of the (cells x genes) raw expression.  ``support_mask`` (bool [cells], default all
+        True): only support cells feed the genes; test cells of a predict graph get gene->cell edges only
+        (preprocess.py:126-134,184-187)."""
         dev = col.device
         C_ = rowptr.shape[0] - 1
         rowptr = rowptr.to(torch.int32).contiguous()
@@ -230,14 +216,18 @@ class CellGeneGraph:
         val, inv_deg = _normalize_on_device(rowptr, raw)
         host = rowptr.cpu().numpy()
         cg = AggCsr(rowptr, col, val, inv_deg, C_, num_genes, build_plan(host, chunk, device=dev), host)
-        # transpose the RAW values, then normalise per gene
-        counts = torch.bincount(col.long(), minlength=num_genes)
+        # transpose the RAW values (support cells only), then normalise per gene
+        rows = torch.repeat_interleave(torch.arange(C_, device=dev, dtype=torch.int32), (rowptr[1:] - rowptr[:-1]).long())
+        s_col, s_raw = col, raw
+        if support_mask is not None:
+            keep = support_mask.to(dev)[rows.long()]
+            rows, s_col, s_raw = rows[keep], col[keep], raw[keep]
+        counts = torch.bincount(s_col.long(), minlength=num_genes)
         t_rowptr = torch.zeros(num_genes + 1, dtype=torch.int64, device=dev)
         torch.cumsum(counts, 0, out=t_rowptr[1:])
-        rows = torch.repeat_interleave(torch.arange(C_, device=dev, dtype=torch.int32), (rowptr[1:] - rowptr[:-1]).long())
-        order = torch.sort(col.long(), stable=True).indices
+        order = torch.sort(s_col.long(), stable=True).indices
         t_col = rows[order].contiguous()
-        t_raw = raw[order].contiguous()
+        t_raw = s_raw[order].contiguous()
         del rows, order
         t_rowptr = t_rowptr.to(torch.int32)
         t_val, t_inv = _normalize_on_device(t_rowptr, t_raw)
