@@ -9,6 +9,7 @@ from ._lib import WgnnError, DST_IS_GENE, NO_ALPHA, SRC_IS_GENE
 from .graph import AggCsr, CellGeneGraph, Plan, build_plan
 from .gnn import GNN, NodeUpdate
 from .api import DeepSortClassifier, DeepSortPredictor
+from .graphed import GraphedForward
 from .ops import agg_bwd_alpha, agg_bwd_src, agg_fwd, weighted_mean_aggregate
 
 __all__ = ["GNN", "NodeUpdate", "DeepSortClassifier", "DeepSortPredictor", "CellGeneGraph", "AggCsr", "Plan", "build_plan", "agg_fwd", "agg_bwd_src",

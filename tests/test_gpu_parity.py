@@ -646,3 +646,19 @@ def test_hip_gradients_match_executed_reference_code(name):
     for k, p in m.named_parameters():
         ref = z["grad." + k]
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=TOL * max(1.0, float(np.abs(ref).max())), err_msg=k)
+
+
+def test_hipgraph_replay_matches_eager():
+    """GraphedForward: the forward captured into a HIP graph replays to the same logits, also on new features."""
+    from scdeepsort_amd.graphed import GraphedForward
+    c = small_case(seed=61)
+    sd = O.init_params(c["dim"], c["hidden"], c["n_classes"], 2, c["G"], seed=13)
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
+    m = make_model(sd, c["dim"], c["hidden"], c["n_classes"], 2, c["G"])
+    x1 = dev(c["feats"]); x2 = dev(np.random.default_rng(9).standard_normal(c["feats"].shape).astype(np.float32))
+    with torch.no_grad():
+        e1, e2 = m(g, x1), m(g, x2)
+    gf = GraphedForward(m, g, x1)
+    assert torch.equal(gf().clone(), e1)
+    assert torch.equal(gf(x2).clone(), e2)
+    assert torch.equal(gf(x1).clone(), e1)
