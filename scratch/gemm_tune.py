@@ -1,0 +1,23 @@
+import os, sys, time, torch, torch.nn.functional as F
+dev='cuda:0'
+shapes=[(100000,400,256),(20000,400,256),(20000,256,256),(100000,256,256),(100000,256,16)]
+def timeit(f,n=30):
+    f(); torch.cuda.synchronize(); t=time.perf_counter()
+    for _ in range(n): f()
+    torch.cuda.synchronize(); return (time.perf_counter()-t)/n*1e6
+xs=[(torch.randn(m,k,device=dev),torch.randn(n,k,device=dev),torch.randn(n,device=dev)) for m,k,n in shapes]
+base=[timeit(lambda: F.linear(x,w)) for x,w,b in xs]
+print('default      ', [round(t,1) for t in base], 'sum', round(sum(base),1))
+try:
+    torch.backends.cuda.preferred_blas_library('hipblaslt')
+    t2=[timeit(lambda: F.linear(x,w)) for x,w,b in xs]
+    print('hipblaslt    ', [round(t,1) for t in t2], 'sum', round(sum(t2),1))
+except Exception as e: print('hipblaslt n/a', e)
+try:
+    torch.backends.cuda.preferred_blas_library('default')
+    import torch.cuda.tunable as tn
+    tn.enable(True); tn.set_max_tuning_duration(200); tn.set_max_tuning_iterations(50)
+    t0=time.time()
+    t3=[timeit(lambda: F.linear(x,w)) for x,w,b in xs]
+    print('tunable      ', [round(t,1) for t in t3], 'sum', round(sum(t3),1), 'tuning took', round(time.time()-t0,1),'s')
+except Exception as e: print('tunable n/a', e)
