@@ -141,8 +141,7 @@ class AggCsr:
         if self._tile_plan is None:
             self._tile_plan = {}
         if block_rows not in self._tile_plan:
-            self._tile_plan[block_rows] = build_tile_plan(self, *auto_tile_geometry(self.n_rows, self.n_cols),
-                                                          block_rows=block_rows)
+            self._tile_plan[block_rows] = build_tile_plan(self, None, None, block_rows=block_rows)
         return self._tile_plan[block_rows]
 
     def subplan(self, row_ids: torch.Tensor) -> Tuple[torch.Tensor, Plan]:
@@ -307,33 +306,55 @@ def auto_tile_geometry(n_rows: int, n_cols: int, n_cus: int = 256) -> Tuple[int,
     if min_tiles >= n_cus:
         return -(-min_tiles // n_cus) * n_cus, 1
     n_row_tiles = -(-n_rows // 250)
-    splits = max(1, min(round(5 * n_cus / n_row_tiles), n_cols // 512 or 1))
+    splits = max(1, min(5 * n_cus // n_row_tiles, n_cols // 512 or 1))       # at most five full rounds over the CUs
     return n_row_tiles, splits
 
 
-def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits: int = 1,
-                    n_cus: int = 256, block_rows: int = 64) -> TilePlan:
+def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits: Optional[int] = 1,
+                    n_cus: int = 256, block_rows: int = 64, balance: bool = True) -> TilePlan:
     """Group the rows of ``csr`` into tiles of <= 256 rows (nnz-balanced across tiles and across the 16
     waves of a tile) and optionally split the column (source) range so hub rows spread over several
-    workgroups.  Pure index arithmetic on the device; runs once per graph."""
+    workgroups.  Pure index arithmetic on the device; runs once per graph.
+
+    ``balance``: a row much heavier than the average wave's share (a hub gene) would make its wave the straggler at
+    every per-block barrier, so it is dealt as k "virtual rows" - its non-zeros round-robin, i.e. evenly inside every
+    source block - that land in different waves (and tiles); each writes a partial sum that ``agg_finalize`` folds in
+    fixed order, exactly like the partial sums of column splits.
+
+    ``n_col_splits=None``: heuristic geometry (``auto_tile_geometry`` on the number of virtual rows)."""
     dev = csr.device
     R, S = csr.n_rows, csr.n_cols
-    min_tiles = -(-R // TILE_ROWS)
+    nnz = (csr.rowptr[1:] - csr.rowptr[:-1]).long()
+    total = int(nnz.sum())
+    # ---- virtual rows
+    k_r = torch.ones(R, dtype=torch.int64, device=dev)
+    if balance and R > 0 and total > 0:
+        tiles_guess = max(n_row_tiles or 0, -(-R // TILE_ROWS), 1)
+        cap = max(64.0, 0.5 * total / (tiles_guess * TILE_WAVES))          # half the average wave's share of a tile
+        k_r = torch.clamp(torch.ceil(nnz.double() / cap).long(), 1, 16)
+    vbase = torch.zeros(R + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(k_r, 0, out=vbase[1:])
+    V = int(vbase[-1])                                                      # number of virtual rows
+    vrow = torch.repeat_interleave(torch.arange(R, device=dev), k_r)        # virtual row -> row
+    vpart = torch.arange(V, device=dev) - vbase[vrow]
+    vnnz = nnz[vrow] // k_r[vrow] + (vpart < nnz[vrow] % k_r[vrow]).long()  # round-robin share of the row's non-zeros
+    min_tiles = -(-V // TILE_ROWS)
+    if n_col_splits is None:
+        n_row_tiles, n_col_splits = auto_tile_geometry(V, S, n_cus)
     if n_row_tiles is None:
         per = max(1, n_cus // max(1, n_col_splits))
         n_row_tiles = -(-min_tiles // per) * per                 # whole number of rounds over the CUs
     n_row_tiles = max(n_row_tiles, min_tiles)
-    nnz = (csr.rowptr[1:] - csr.rowptr[:-1]).long()
-    order = torch.sort(nnz, descending=True, stable=True).indices          # row ids, longest first
-    p = torch.arange(R, device=dev)
+    order = torch.sort(vnnz, descending=True, stable=True).indices          # virtual row ids, longest first
+    p = torch.arange(V, device=dev)
     tile = _snake(p, n_row_tiles)
     rnd = p // n_row_tiles                                                  # local index inside the tile (desc. nnz)
-    if int(rnd.max()) >= TILE_ROWS:
+    if V and int(rnd.max()) >= TILE_ROWS:
         raise ValueError("tile overflow")
     wave = _snake(rnd, TILE_WAVES)
     slot_in_wave = rnd // TILE_WAVES
     local = wave * (TILE_ROWS // TILE_WAVES) + slot_in_wave
-    # column splits on 64-row block boundaries
+    # column splits on block boundaries
     blk = block_rows
     per_split = -(-(-(-S // blk)) // n_col_splits) * blk
     bounds = torch.arange(n_col_splits + 1, device=dev, dtype=torch.int64) * per_split
@@ -341,49 +362,41 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
     bounds = bounds.clamp(max=S)
     items = torch.full((n_col_splits, n_row_tiles, TILE_ROWS, 4), -1, dtype=torch.int32, device=dev)
     items[..., 1:3] = 0
-    rp = csr.rowptr.long()
-    if n_col_splits == 1:
-        seg_b = rp[:-1][order].unsqueeze(0)
-        seg_e = rp[1:][order].unsqueeze(0)
-    else:
-        # first nnz of every row whose column >= bound: rows are sorted by column, so row*S + col is globally sorted
-        rows_of = torch.repeat_interleave(torch.arange(R, device=dev), nnz)
-        keys = rows_of * S + csr.col.long()
-        q = (order.unsqueeze(0) * S + bounds.unsqueeze(1))                   # [splits+1, R]
-        cut = torch.searchsorted(keys, q.reshape(-1)).reshape(n_col_splits + 1, R)
-        del keys, rows_of
-        seg_b, seg_e = cut[:-1], cut[1:]
+    # partial-sum slots: a row needs them when it is split along the columns or into virtual rows
+    n_parts_r = k_r * n_col_splits
+    needs = n_parts_r > 1
+    pbase = torch.zeros(R + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(torch.where(needs, n_parts_r, torch.zeros_like(n_parts_r)), 0, out=pbase[1:])
+    n_part = int(pbase[-1])
+    o_row, o_part = vrow[order], vpart[order]
     for k in range(n_col_splits):
-        items[k, tile, local, 0] = order.to(torch.int32)
-        items[k, tile, local, 1] = seg_b[k].to(torch.int32)
-        items[k, tile, local, 2] = seg_e[k].to(torch.int32)
-        if n_col_splits > 1:
-            items[k, tile, local, 3] = (order * n_col_splits + k).to(torch.int32)
+        items[k, tile, local, 0] = o_row.to(torch.int32)
+        pslot = pbase[o_row] + o_part * n_col_splits + k
+        items[k, tile, local, 3] = torch.where(needs[o_row], pslot, torch.full_like(pslot, -1)).to(torch.int32)
     hdr = torch.empty((n_col_splits, n_row_tiles, 2), dtype=torch.int32, device=dev)
     hdr[..., 0] = bounds[:-1].to(torch.int32).unsqueeze(1)
     hdr[..., 1] = bounds[1:].to(torch.int32).unsqueeze(1)
-    if n_col_splits > 1:
-        ar = torch.arange(R, device=dev, dtype=torch.int32)
-        long_rows = torch.stack([ar, ar * n_col_splits, torch.full_like(ar, n_col_splits), torch.zeros_like(ar)], 1).contiguous()
-        n_part = R * n_col_splits
-    else:
-        long_rows = torch.empty((0, 4), dtype=torch.int32, device=dev)
-        n_part = 0
+    lr = torch.nonzero(needs).squeeze(1)
+    long_rows = torch.stack([lr, pbase[lr], n_parts_r[lr], torch.zeros_like(lr)], 1).to(torch.int32).contiguous() \
+        if lr.numel() else torch.empty((0, 4), dtype=torch.int32, device=dev)
     # ---- entries: the CSR re-ordered by (tile, block, wave, destination slot)
-    tile_r = torch.empty(R, dtype=torch.int64, device=dev); tile_r[order] = tile
-    wave_r = torch.empty(R, dtype=torch.int64, device=dev); wave_r[order] = wave
-    slot_r = torch.empty(R, dtype=torch.int64, device=dev); slot_r[order] = slot_in_wave
+    tile_v = torch.empty(V, dtype=torch.int64, device=dev); tile_v[order] = tile
+    wave_v = torch.empty(V, dtype=torch.int64, device=dev); wave_v[order] = wave
+    slot_v = torch.empty(V, dtype=torch.int64, device=dev); slot_v[order] = slot_in_wave
     nblk_max = max(1, per_split // blk)
     rows_of = torch.repeat_interleave(torch.arange(R, device=dev), nnz)
+    pos = torch.arange(rows_of.shape[0], device=dev) - csr.rowptr.long()[rows_of]
+    virt = vbase[rows_of] + pos % k_r[rows_of]                             # the virtual row every non-zero belongs to
+    del pos, rows_of
     colv = csr.col.long()
     ksplit = torch.div(colv, per_split, rounding_mode="floor")
     rel = colv - ksplit * per_split
-    key = ((ksplit * n_row_tiles + tile_r[rows_of]) * nblk_max + torch.div(rel, blk, rounding_mode="floor")) * TILE_WAVES \
-        + wave_r[rows_of]
-    meta = ((slot_r[rows_of] << 8) | (rel % blk)).to(torch.int32)
+    key = ((ksplit * n_row_tiles + tile_v[virt]) * nblk_max + torch.div(rel, blk, rounding_mode="floor")) * TILE_WAVES \
+        + wave_v[virt]
+    meta = ((slot_v[virt] << 8) | (rel % blk)).to(torch.int32)
     del ksplit, rel, colv
-    key = key * (TILE_ROWS // TILE_WAVES) + slot_r[rows_of]
-    del rows_of
+    key = key * (TILE_ROWS // TILE_WAVES) + slot_v[virt]
+    del virt
     perm = torch.sort(key, stable=True).indices
     n_seg = n_col_splits * n_row_tiles * nblk_max * TILE_WAVES
     counts = torch.bincount(torch.div(key, TILE_ROWS // TILE_WAVES, rounding_mode="floor"), minlength=n_seg)
