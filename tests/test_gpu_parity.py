@@ -667,3 +667,27 @@ def test_hipgraph_replay_matches_eager():
     assert torch.equal(gf().clone(), e1)
     assert torch.equal(gf(x2).clone(), e2)
     assert torch.equal(gf(x1).clone(), e1)
+
+
+def test_integration_md_ctypes_stub_works_as_documented():
+    """The reference-side binding shown in INTEGRATION.md section 2b is executed verbatim (the python block is read
+    from the document) on a small block and compared with the oracle."""
+    import re
+    from pathlib import Path
+    from scdeepsort_amd.graph import build_plan
+    text = (Path(sda.__file__).resolve().parent.parent / "INTEGRATION.md").read_text()
+    block = re.search(r"### 2b\..*?```python\n(.*?)```", text, re.S).group(1)
+    block = block.replace('C.CDLL("scdeepsort_amd/libwgnn_hip.so")', f'C.CDLL("{Path(sda.__file__).resolve().parent / "libwgnn_hip.so"}")')
+    ns = {}
+    exec(block, ns)
+    c = small_case(cells=60, genes=37, dim=32, seed=71, test_cells=0)
+    g = sda.CellGeneGraph.from_expression(c["expr"], device=DEV)
+    cg = O.build_csr_graph(c["expr"])
+    G = c["G"]
+    alpha = np.random.default_rng(1).uniform(0.5, 1.5, G + 2).astype(np.float32)
+    bias = np.random.default_rng(2).standard_normal(32).astype(np.float32)
+    zc, _ = O.csr_aggregate(cg, alpha, c["feats"][:G].astype(np.float64), c["feats"][G:].astype(np.float64))
+    items = build_plan(g.cg.rowptr_host, 2048, device=DEV).items
+    out = ns["block_compute_mean"](g.cg.rowptr, g.cg.col, g.cg.val, dev(alpha), dev(c["feats"][:G]), dev(c["feats"][G:]), items,
+                                   src_is_gene=True, gene_num=G, bias=dev(bias), relu=True)
+    np.testing.assert_allclose(out.cpu().numpy(), np.maximum(zc + bias, 0), atol=TOL)
