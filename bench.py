@@ -180,6 +180,12 @@ def main():
                 "alg_bytes_per_launch": dom["alg_bytes"], "avg_launch_ms": dom["avg_ms"], "passes": passes,
                 "forward_alg_bytes": engine.forward_alg_bytes(cfg.dense_dim, feats_g.element_size()),
                 "forward_achieved_GBs": round(engine.forward_alg_bytes(cfg.dense_dim, feats_g.element_size()) / ms_per_step / 1e6, 1),
+                # the resource that actually bounds the tile kernel: per launch every non-zero reads one D*4-byte source row
+                # from LDS and every tile streams its source range into LDS once
+                "on_chip": {"lds_read_bytes": dom["nnz"] * dom["D"] * 4,
+                            "lds_achieved_TBs": round(dom["nnz"] * dom["D"] * 4 / dom["avg_ms"] / 1e9, 1),
+                            "lds_peak_TBs": 157.0, "lds_frac": round(dom["nnz"] * dom["D"] * 4 / dom["avg_ms"] / 1e9 / 157.0, 3),
+                            "fp32_fma_TFLOPs": round(2 * dom["nnz"] * dom["D"] / dom["avg_ms"] / 1e9, 1), "fp32_vector_peak_TFLOPs": 157.3},
                 "note": "AI vs algorithmic bytes is 50-110 flop/B (> fp32 ridge ~20): the gather of nnz*D*4 B "
                         "from L2/MALL and fp32 FMA issue bound this kernel before HBM does (DESIGN.md section 4)"}
 
