@@ -153,3 +153,14 @@ def test_generated_flat_pipeline_is_in_sync_and_well_formed(tmp_path):
         wait = int(re.search(r"s_waitcnt lgkmcnt\((\d+)\)", body).group(1))
         assert n_reads == (3 if p < 31 else 0) and wait == n_reads, (p, n_reads, wait)
         assert len(re.findall(r"v_pk_fma_f32", body)) == 4
+
+
+def test_plan_heuristics():
+    from scdeepsort_amd.graph import auto_chunk, auto_tile_geometry
+    assert auto_chunk(0) == 256 and auto_chunk(2_000_000) == 256 and auto_chunk(80_000_000) == 2048
+    assert all(auto_chunk(n) in (256, 512, 1024, 2048) for n in (1, 3_000_000, 6_000_000, 10_000_000, 10 ** 9))
+    # cells side of cfg3: two full rounds over 256 CUs, no column split; gene side: <= five rounds, column-split
+    assert auto_tile_geometry(100_000, 20_000) == (512, 1)
+    rt, cs = auto_tile_geometry(20_600, 100_000)
+    assert rt * 250 >= 20_600 and cs > 1 and rt * cs <= 5 * 256
+    assert auto_tile_geometry(300, 100) == (2, 1)
