@@ -116,10 +116,13 @@ def agg_fwd(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, self_idx: int
 
 def agg_bwd_src(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, g: torch.Tensor,
                 h_src: Optional[torch.Tensor], dalpha: Optional[torch.Tensor] = None,
-                dh_src: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+                dh_src: Optional[torch.Tensor] = None, accumulate: bool = False,
+                dst_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
     """K2 ``wgnn_agg_bwd_src``: gradient w.r.t. the gathered rows (transposed SpMM);
-    for SRC_IS_GENE also writes dalpha[0:n_src] = <h_src[s], T[s]>."""
+    for SRC_IS_GENE also writes dalpha[0:n_src] = <h_src[s], T[s]>.  ``dst_scale`` replaces the per-destination
+    factor 1/(deg+1) (``csr.inv_deg``), e.g. ones for the backward of a plain weighted sum."""
     dev = _require_cuda(g, h_src, alpha)
+    inv_deg = csr.inv_deg if dst_scale is None else dst_scale.float().contiguous()
     t = csr.transposed()
     g = _rowmajor(g.float())
     D = g.shape[1]
@@ -135,7 +138,7 @@ def agg_bwd_src(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, g: torch.
     if TILED_MIN_WORK is not None and D <= 256 and csr.nnz * D >= TILED_MIN_WORK:
         # K2t: LDS-streamed kernel over the transposed structure; per-destination factors folded into g once
         tp = t.tile_plan(tiled_block_rows(D))
-        scale = csr.inv_deg if mode != DST_IS_GENE else csr.inv_deg * alpha[: csr.n_rows]
+        scale = inv_deg if mode != DST_IS_GENE else inv_deg * alpha[: csr.n_rows]
         g = g.contiguous()
         scratch = torch.empty_like(g)
         part = torch.empty(tp.n_partials * D, dtype=torch.float32, device=dev) if tp.n_partials else None
@@ -150,7 +153,7 @@ def agg_bwd_src(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, g: torch.
         return dh_src
     part = _partials(t.plan, D, dev)
     rc = _lib.lib().wgnn_agg_bwd_src(
-        _ptr(t.rowptr), _ptr(t.col), _ptr(t.val), _ptr(alpha), mode, _ptr(csr.inv_deg),
+        _ptr(t.rowptr), _ptr(t.col), _ptr(t.val), _ptr(alpha), mode, _ptr(inv_deg),
         _ptr(g), g.stride(0), _ptr(h_src), h_src.stride(0) if h_src is not None else 0,
         _ptr(dh_src), dh_src.stride(0), _ptr(dalpha), int(accumulate), t.n_rows, D,
         _ptr(t.plan.items), t.plan.n_items, _ptr(t.plan.long_rows) if t.plan.n_long else None, t.plan.n_long,
@@ -342,12 +345,7 @@ class _WeightedSum(torch.autograd.Function):
         if ones is None or ones.shape[0] != csr.n_rows:
             ones = torch.ones(csr.n_rows, dtype=torch.float32, device=g.device)
             csr._ones = ones
-        saved, csr.inv_deg = csr.inv_deg, ones                # plain A^T g: unit per-destination factor
-        try:
-            dh = agg_bwd_src(csr, None, NO_ALPHA, g, None)
-        finally:
-            csr.inv_deg = saved
-        return dh, None
+        return agg_bwd_src(csr, None, NO_ALPHA, g, None, dst_scale=ones), None      # plain A^T g: unit factor
 
 
 def weighted_sum(csr: AggCsr, h_src: torch.Tensor) -> torch.Tensor:
