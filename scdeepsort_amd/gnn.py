@@ -72,7 +72,7 @@ class GNN(nn.Module):
         carried as 256 columns with zero weights / bias in the padding (exact: the extra columns stay 0 through ReLU
         and meet zero weight columns in the next layer)."""
         from . import ops
-        if H < 256 and ops.TILED_MIN_WORK is not None and g.cg.nnz * 256 >= ops.TILED_MIN_WORK:
+        if H < 256 and ops.TILED_MIN_WORK is not None and g.cg.nnz * H >= ops.TILED_MIN_WORK:
             return 256
         return H
 

@@ -50,7 +50,7 @@ def _dtype_code(t: torch.Tensor) -> int:
 PROFILE = None
 DEBUG_FLAGS = 0      # ablation switches of the tiled kernel (timing experiments only)
 # K1 dispatch: passes with nnz*D above this go to the LDS-streamed kernel (None = always row-wave)
-TILED_MIN_WORK = 2_000_000_000
+TILED_MIN_WORK = 500_000_000        # nnz*D above which the LDS-streamed kernels win (measured crossover: ~2 M edges at D = 256)
 
 
 def _partials(plan: Plan, D: int, device) -> Optional[torch.Tensor]:

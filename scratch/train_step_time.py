@@ -11,8 +11,8 @@ feats=S.synth_features(G+C,cfg.dense_dim,device=dev); y=torch.arange(C,device=de
 opt=torch.optim.Adam(m.parameters(),lr=1e-3,weight_decay=5e-4)
 def step():
     loss=F.cross_entropy(m(g,feats),y,reduction='sum'); opt.zero_grad(); loss.backward(); opt.step(); return loss
-for thr,name in ((None,'row-wave backward'),(2_000_000_000,'tiled backward')):
-    ops.TILED_MIN_WORK=2_000_000_000
+for thr,name in ((None,"row-wave backward"),(500_000_000,"tiled backward")):
+    ops.TILED_MIN_WORK=500_000_000
     import scdeepsort_amd.ops as O2
     step(); torch.cuda.synchronize()
     # forward always tiled; toggle only the backward dispatch by monkeypatching inside autograd: simplest = set threshold during backward
@@ -21,5 +21,5 @@ for thr,name in ((None,'row-wave backward'),(2_000_000_000,'tiled backward')):
     t=time.perf_counter()
     for _ in range(3):
         loss=F.cross_entropy(m(g,feats),y,reduction='sum'); opt.zero_grad()
-        ops.TILED_MIN_WORK=thr; loss.backward(); ops.TILED_MIN_WORK=2_000_000_000; opt.step()
+        ops.TILED_MIN_WORK=thr; loss.backward(); ops.TILED_MIN_WORK=500_000_000; opt.step()
     torch.cuda.synchronize(); print(name, (time.perf_counter()-t)/3*1e3,'ms per full-graph training step (fwd+bwd+Adam), loss',float(loss))
