@@ -299,14 +299,17 @@ def _snake(p: torch.Tensor, n: int) -> torch.Tensor:
     return torch.where(r % 2 == 0, q, n - 1 - q)
 
 
-def auto_tile_geometry(n_rows: int, n_cols: int, n_cus: int = 256) -> Tuple[int, int]:
-    """(n_row_tiles, n_col_splits): a whole number of rounds over the CUs; few-row operands (the gene side)
-    are split along the source axis so that hub rows spread over several workgroups."""
+def auto_tile_geometry(n_rows: int, n_cols: int, n_cus: int = 256, nnz: Optional[int] = None) -> Tuple[int, int]:
+    """(n_row_tiles, n_col_splits), from sweeps at 10k..100k cells (``scratch/geom_mid.py``, ``geom_sweep.py``):
+    * many rows (>= 40k): whole rounds of ~195..256-row tiles over the CUs, no column split;
+    * fewer rows (the gene side; the cell side of small graphs): ~250-row tiles, and the source axis split so that
+      hub rows spread over several workgroups and the launch has ~nnz/50k tiles (between 160 and five full rounds)."""
     min_tiles = -(-n_rows // TILE_ROWS)
-    if min_tiles >= n_cus:
+    if n_rows >= 40_000:
         return -(-min_tiles // n_cus) * n_cus, 1
-    n_row_tiles = -(-n_rows // 250)
-    splits = max(1, min(5 * n_cus // n_row_tiles, n_cols // 512 or 1))       # at most five full rounds over the CUs
+    n_row_tiles = max(1, -(-n_rows // 250))
+    target = 5 * n_cus if nnz is None else min(5 * n_cus, max(160, nnz // 50_000))
+    splits = max(1, min(round(target / n_row_tiles), 5 * n_cus // n_row_tiles, n_cols // 512 or 1))
     return n_row_tiles, splits
 
 
@@ -340,7 +343,7 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
     vnnz = nnz[vrow] // k_r[vrow] + (vpart < nnz[vrow] % k_r[vrow]).long()  # round-robin share of the row's non-zeros
     min_tiles = -(-V // TILE_ROWS)
     if n_col_splits is None:
-        n_row_tiles, n_col_splits = auto_tile_geometry(V, S, n_cus)
+        n_row_tiles, n_col_splits = auto_tile_geometry(V, S, n_cus, total)
     if n_row_tiles is None:
         per = max(1, n_cus // max(1, n_col_splits))
         n_row_tiles = -(-min_tiles // per) * per                 # whole number of rounds over the CUs
