@@ -319,7 +319,7 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
     waves of a tile) and optionally split the column (source) range so hub rows spread over several
     workgroups.  Pure index arithmetic on the device; runs once per graph.
 
-    ``balance``: a row much heavier than the average wave's share (a hub gene) would make its wave the straggler at
+    ``balance`` (few-row operands only, i.e. the gene side): a row heavier than half the average wave's share (a hub gene) would make its wave the straggler at
     every per-block barrier, so it is dealt as k "virtual rows" - its non-zeros round-robin, i.e. evenly inside every
     source block - that land in different waves (and tiles); each writes a partial sum that ``agg_finalize`` folds in
     fixed order, exactly like the partial sums of column splits.
@@ -331,7 +331,7 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
     total = int(nnz.sum())
     # ---- virtual rows
     k_r = torch.ones(R, dtype=torch.int64, device=dev)
-    if balance and R > 0 and total > 0:
+    if balance and 0 < R < 40_000 and total > 0:           # many-row operands: every row is a small fraction of a tile
         tiles_guess = max(n_row_tiles or 0, -(-R // TILE_ROWS), 1)
         cap = max(64.0, 0.5 * total / (tiles_guess * TILE_WAVES))          # half the average wave's share of a tile
         k_r = torch.clamp(torch.ceil(nnz.double() / cap).long(), 1, 16)
