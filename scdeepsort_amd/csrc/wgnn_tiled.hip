@@ -1,24 +1,27 @@
-// wgnn_tiled.hip - LDS-streamed aggregation kernel for CDNA4 (gfx950).
+// wgnn_tiled.hip - LDS-streamed aggregation kernels for CDNA4 (gfx950).
 //
 // Same arithmetic as agg_main (reference models/gnn.py:47-56,65 + fused bias/ReLU, gnn.py:20-22),
 // different data movement.  The row-wave kernel re-gathers every source row from L2/MALL once per
 // non-zero (nnz*D*4 B = 82 GB per pass at BASELINE cfg3) and is bound by the ~64 B/clk/CU vector
 // memory path.  Here one 1024-thread workgroup (16 waves, one per CU) owns a TILE of up to 256
 // destination rows - 16 per wave, accumulators resident in VGPRs (16 x float4 per lane) - and the
-// SOURCE table is streamed through LDS in blocks of 64 rows (64 KiB at D=256) with the async
+// SOURCE table is streamed through LDS in blocks of `kb` rows (78 KiB at D=256) with the async
 // global->LDS DMA (global_load_lds_dwordx4), double-buffered.  Every staged source row is consumed
 // by all rows of the tile that reference it, so the per-non-zero gather becomes a conflict-free
 // ds_read_b128 (256 B/clk/CU) and global traffic drops to (rows/256) x |source table|.
 //
 // The edges of a tile are pre-sorted at plan time into (block, wave, destination row) order
 // ("entries": {dst_slot<<8 | src_row_in_block, weight}), so that in every block a wave fetches its
-// share with ONE coalesced 8-byte load per lane, issued a full block ahead (its latency hides behind
-// the previous block's FMAs), finds each row's run with one compare + ballot, and broadcasts
-// (source row, weight) with v_readlane.  alpha[k(e)] for gene->cell edges is a per-source-row factor,
-// so it is applied to the source table once (scale_rows) instead of per edge - which is also the
-// reference's own multiply order, (h*alpha)*w.  Tiles carry a column range so that hub rows (genes
-// expressed in ~every cell) are split across workgroups; their partial sums are folded by
-// agg_finalize in a fixed order (deterministic, no atomics).
+// share ("chunk") with ONE coalesced 8-byte load per lane, issued ahead of time so that its latency
+// hides behind earlier blocks' FMAs, and broadcasts (source row, weight) with v_readlane / an LDS
+// broadcast read.  alpha[k(e)] for gene->cell edges is a per-source-row factor, so it is applied to
+// the source table once (scale_rows) instead of per edge - which is also the reference's own
+// multiply order, (h*alpha)*w.  Tiles carry a column range so that hub rows (genes expressed in
+// ~every cell) are split across workgroups; their partial sums are folded by agg_finalize in a
+// fixed order (deterministic, no atomics).
+//
+// Two kernels: agg_tiled (any D <= 256: per-row ballot visits, compiler-scheduled) and
+// agg_tiled_flat4 (D == 256: generated straight-line ISA, see below and gen_flat_asm.py).
 #include <type_traits>
 #include "wgnn_common.h"
 #include "wgnn_flat_asm.inc"
