@@ -43,8 +43,20 @@ def auto_chunk(nnz: int) -> int:
     return c
 
 
+_EMPTY: dict = {}
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
-    return None if t is None else t.data_ptr()
+    """Device address for the C ABI.  An EMPTY tensor (e.g. col / val of a graph without a single edge) has a null
+    data pointer, which the ABI would reject as a missing argument: it gets the address of a small per-device
+    placeholder instead (never dereferenced - the row pointers say there is nothing to read)."""
+    if t is None:
+        return None
+    if t.numel() == 0 and t.is_cuda:
+        if t.device not in _EMPTY:
+            _EMPTY[t.device] = torch.zeros(64, dtype=torch.int32, device=t.device)
+        return _EMPTY[t.device].data_ptr()
+    return t.data_ptr()
 
 
 def _stream(device: torch.device) -> Optional[int]:

@@ -691,3 +691,21 @@ def test_integration_md_ctypes_stub_works_as_documented():
     out = ns["block_compute_mean"](g.cg.rowptr, g.cg.col, g.cg.val, dev(alpha), dev(c["feats"][:G]), dev(c["feats"][G:]), items,
                                    src_is_gene=True, gene_num=G, bias=dev(bias), relu=True)
     np.testing.assert_allclose(out.cpu().numpy(), np.maximum(zc + bias, 0), atol=TOL)
+
+
+def test_graph_without_any_edge():
+    """Degenerate operand: no expressed gene at all - every node only has its self-loop (deg+1 = 1)."""
+    expr = sp.csr_matrix((5, 7), dtype=np.float32)
+    c = dict(dim=8, hidden=8, n_classes=3)
+    sd = O.init_params(8, 8, 3, 2, 7, seed=21)
+    feats = (0.5 * np.random.default_rng(4).standard_normal((12, 8))).astype(np.float32)
+    g = sda.CellGeneGraph.from_expression(expr, device=DEV)
+    assert g.cg.nnz == 0 and g.gc.nnz == 0
+    m = make_model(sd, 8, 8, 3, 2, 7)
+    with torch.no_grad():
+        got = m(g, dev(feats)).cpu().numpy()
+    want = O.csr_forward(sd, O.build_csr_graph(expr), feats, 2)
+    np.testing.assert_allclose(got, want, atol=TOL)
+    rg = O.build_reference_graph(expr)
+    want2 = O.nodeflow_forward(sd, rg, torch.from_numpy(feats), np.arange(7, 12), 2).numpy()
+    np.testing.assert_allclose(got, want2, atol=TOL)
