@@ -74,13 +74,16 @@ class GNN(nn.Module):
         from . import ops
         if H < 256 and ops.TILED_MIN_WORK is not None and g.cg.nnz * H >= ops.TILED_MIN_WORK:
             return 256
-        return H
+        return -(-H // 4) * 4                              # the kernels move float4s: widths are multiples of 4
 
     def _layer(self, g: CellGeneGraph, layer: NodeUpdate, h_g: torch.Tensor, h_c: torch.Tensor,
                want_genes: bool, cell_rows: Optional[torch.Tensor]):
         G = self.gene_num
         W, b = layer.fc_neigh.weight, layer.fc_neigh.bias
         project_first = self.order == "project_first" or (self.order == "auto" and W.shape[0] <= W.shape[1])
+        if h_g.shape[1] % 4:                               # e.g. dense_dim = 50: zero feature columns up to a multiple of 4
+            extra = -h_g.shape[1] % 4
+            h_g, h_c = F.pad(h_g, (0, extra)), F.pad(h_c, (0, extra))
         if h_g.shape[1] > W.shape[1]:                      # input carried padded (see _pad_width): zero weight columns
             W = F.pad(W, (0, h_g.shape[1] - W.shape[1]))
         Hp = self._pad_width(g, W.shape[0]) if project_first else W.shape[0]
@@ -160,9 +163,15 @@ class GNN(nn.Module):
         for i, (layer, (cb, gb)) in enumerate(zip(self.layers, nodeflow.blocks)):
             if self.dropout is not None:
                 h_g, h_c = self.dropout(h_g), self.dropout(h_c)
+            if h_g.shape[1] % 4:                           # the kernels move float4s: zero columns up to a multiple of 4
+                extra = -h_g.shape[1] % 4
+                h_g, h_c = F.pad(h_g, (0, extra)), F.pad(h_c, (0, extra))
 
             def update(z):
-                x = layer.fc_neigh(z)
+                W = layer.fc_neigh.weight
+                if z.shape[1] > W.shape[1]:
+                    W = F.pad(W, (0, z.shape[1] - W.shape[1]))
+                x = F.linear(z, W, layer.fc_neigh.bias)
                 if layer.activation is not None:
                     x = layer.activation(x)
                 if layer.norm is not None:

@@ -709,3 +709,25 @@ def test_graph_without_any_edge():
     rg = O.build_reference_graph(expr)
     want2 = O.nodeflow_forward(sd, rg, torch.from_numpy(feats), np.arange(7, 12), 2).numpy()
     np.testing.assert_allclose(got, want2, atol=TOL)
+
+
+@pytest.mark.parametrize("order", ["auto", "project_first", "aggregate_first"])
+@pytest.mark.parametrize("dims", [(50, 30), (30, 50), (7, 5)])
+def test_widths_that_are_not_multiples_of_four(order, dims):
+    """The reference accepts any dense_dim / hidden_dim; the kernels move float4s, so the model carries such widths
+    zero-padded (features, weights) - logits and embedding width are unchanged."""
+    dim, hidden = dims
+    c = small_case(cells=70, genes=45, dim=dim, hidden=hidden, n_classes=4, seed=81)
+    sd = O.init_params(dim, hidden, 4, 2, c["G"], seed=14)
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
+    m = make_model(sd, dim, hidden, 4, 2, c["G"], order)
+    want = O.csr_forward(sd, O.build_csr_graph(c["expr"], c["support_mask"]), c["feats"], 2)
+    with torch.no_grad():
+        got = m(g, dev(c["feats"]))
+        emb = m.embed(g, dev(c["feats"]))
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL)
+    assert emb.shape[1] == hidden
+    if order == "auto":                                   # the sampled-NodeFlow path with an all-neighbours draw
+        with torch.no_grad():
+            big = m(g, dev(c["feats"]), num_neighbors=10 ** 6, generator=torch.Generator(device=DEV).manual_seed(3))
+        np.testing.assert_allclose(big.cpu().numpy(), want, atol=TOL)
