@@ -731,3 +731,26 @@ def test_widths_that_are_not_multiples_of_four(order, dims):
         with torch.no_grad():
             big = m(g, dev(c["feats"]), num_neighbors=10 ** 6, generator=torch.Generator(device=DEV).manual_seed(3))
         np.testing.assert_allclose(big.cpu().numpy(), want, atol=TOL)
+
+
+def test_predict_graph_with_only_test_cells_and_tiny_graphs():
+    """(a) no support cell at all: genes have no in-edge besides their self-loop, cells still gather from genes
+    (preprocess.py:184-187); (b) a 1 x 1 graph."""
+    c = small_case(cells=30, genes=20, dim=16, hidden=12, n_classes=3, seed=91)
+    mask = np.zeros(30, bool)
+    sd = O.init_params(16, 12, 3, 2, 20, seed=15)
+    g = sda.CellGeneGraph.from_expression(c["expr"], mask, device=DEV)
+    assert g.gc.nnz == 0 and g.cg.nnz == c["expr"].nnz
+    m = make_model(sd, 16, 12, 3, 2, 20)
+    with torch.no_grad():
+        got = m(g, dev(c["feats"])).cpu().numpy()
+    np.testing.assert_allclose(got, O.csr_forward(sd, O.build_csr_graph(c["expr"], mask), c["feats"], 2), atol=TOL)
+    rg = O.build_reference_graph(c["expr"], mask)
+    np.testing.assert_allclose(got, O.nodeflow_forward(sd, rg, torch.from_numpy(c["feats"]), np.arange(20, 50), 2).numpy(), atol=TOL)
+    one = sp.csr_matrix(np.array([[2.5]], dtype=np.float32))
+    sd1 = O.init_params(4, 4, 2, 2, 1, seed=16)
+    f1 = np.array([[0.3, -1.0, 0.5, 2.0], [1.5, 0.25, -0.75, 0.1]], dtype=np.float32)
+    g1 = sda.CellGeneGraph.from_expression(one, device=DEV)
+    with torch.no_grad():
+        got1 = make_model(sd1, 4, 4, 2, 2, 1)(g1, dev(f1)).cpu().numpy()
+    np.testing.assert_allclose(got1, O.csr_forward(sd1, O.build_csr_graph(one), f1, 2), atol=TOL)
