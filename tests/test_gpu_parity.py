@@ -609,6 +609,14 @@ def test_narrow_hidden_is_carried_as_256_columns_on_the_tiled_path(hidden):
         ref = grads_ref[n].numpy()
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=TOL * max(1.0, float(np.abs(ref).max())), err_msg=n)
     assert m.embed(g, dev(c["feats"])).shape[1] == hidden
+    ops.TILED_MIN_WORK = 1
+    try:                                                  # seed subset on the padded path (last layer: row-wave kernel, compact rows)
+        ids = torch.tensor([G + 5, G + 0, G + 77, G + 299], device=DEV)
+        with torch.no_grad():
+            sub = m(g, dev(c["feats"]), seeds=ids)
+    finally:
+        ops.TILED_MIN_WORK = saved
+    np.testing.assert_allclose(sub.cpu().numpy(), logits_ref.detach().numpy()[[5, 0, 77, 299]], atol=TOL)
 
 
 @pytest.mark.parametrize("name", ["refcode_train", "refcode_predict", "refcode_1layer"])
