@@ -100,8 +100,23 @@ class ShardedWgnn:
         return self._eye
 
     def _weights(self):
+        """(W, b) per layer + head.  On graphs that run the LDS-streamed kernels a hidden width below 256 is carried
+        zero-padded to 256 columns (``GNN._pad_width``): pad rows / bias of every layer, input columns of the next."""
         m = self.model
-        return [(l.fc_neigh.weight, l.fc_neigh.bias) for l in m.layers] + [(m.linear.weight, m.linear.bias)]
+        out, width_in = [], None
+        for l in m.layers:
+            W, b = l.fc_neigh.weight, l.fc_neigh.bias
+            if width_in is not None and width_in > W.shape[1]:
+                W = F.pad(W, (0, width_in - W.shape[1]))
+            Hp = m._pad_width(self.graph, W.shape[0])
+            if Hp != W.shape[0]:
+                W, b = F.pad(W, (0, 0, 0, Hp - W.shape[0])), F.pad(b, (0, Hp - b.shape[0]))
+            out.append((W, b))
+            width_in = W.shape[0]
+        Wo = m.linear.weight
+        if width_in is not None and width_in > Wo.shape[1]:
+            Wo = F.pad(Wo, (0, width_in - Wo.shape[1]))
+        return out + [(Wo, m.linear.bias)]
 
     def train_step(self, feats_g, feats_c_local, labels_local, optimizer, seeds_local=None) -> float:
         """Data-parallel full-batch step (cfg4): local CE-sum loss, SUM all-reduce of gradients, identical Adam step."""

@@ -762,3 +762,45 @@ def test_predict_graph_with_only_test_cells_and_tiny_graphs():
     with torch.no_grad():
         got1 = make_model(sd1, 4, 4, 2, 2, 1)(g1, dev(f1)).cpu().numpy()
     np.testing.assert_allclose(got1, O.csr_forward(sd1, O.build_csr_graph(one), f1, 2), atol=TOL)
+
+
+def test_sharded_engine_carries_narrow_hidden_padded():
+    """ShardedWgnn on the LDS-streamed path: hidden 32 carried as 256 columns through both layers and the head; two
+    simulated shards (partial gene sums added by hand) reproduce the unsharded logits."""
+    from scdeepsort_amd import ops, synthetic as S
+    from scdeepsort_amd.sharded import ShardedWgnn
+    from scdeepsort_amd.dist import shard_range
+    G, C, Din, H = 300, 1000, 40, 32
+    rp, col, val = S.synth_expression(C, G, 0.08, device=DEV)
+    torch.manual_seed(1)
+    m = sda.GNN(Din, H, 5, 2, G, activation=F.relu).to(DEV).eval()
+    with torch.no_grad():
+        m.alpha.uniform_(0.5, 1.5)
+    feats = S.synth_features(G + C, Din, device=DEV)
+    with torch.no_grad():
+        want = m(sda.CellGeneGraph.from_device_csr(rp, col, val, G), feats)
+    saved = ops.TILED_MIN_WORK
+    ops.TILED_MIN_WORK = 1
+    try:
+        with torch.no_grad():
+            shards = []
+            for r in range(2):
+                lo, hi = shard_range(C, r, 2)
+                b, e = int(rp[lo]), int(rp[hi])
+                shards.append((lo, hi, (rp[lo:hi + 1] - rp[lo]).clone(), col[b:e].clone(), val[b:e].clone()))
+            stats = [ShardedWgnn.gene_stats(c_, v_, G) for _, _, _, c_, v_ in shards]
+            gstats = (stats[0][0] + stats[1][0], stats[0][1] + stats[1][1])
+            eng = [ShardedWgnn.build(m, r_, c_, v_, G, global_stats=gstats) for _, _, r_, c_, v_ in shards]
+            (W1, b1), (W2, b2), (Wo, bo) = eng[0]._weights()
+            assert W1.shape == (256, Din) and W2.shape == (256, 256) and Wo.shape == (5, 256)
+            p_g = F.linear(feats[:G], W1)
+            p_c = [F.linear(feats[G + lo:G + hi], W1) for lo, hi, *_ in shards]
+            new_c = [e._ops().cells_layer(p_g, pc, b1, True) for e, pc in zip(eng, p_c)]
+            total = sum(e._ops().genes_partial(pc) for e, pc in zip(eng, p_c))
+            h_g1 = eng[0]._ops().genes_finish(total, p_g, b1, True)
+            p_g2 = F.linear(h_g1, W2)
+            out = [e._ops().cells_layer(p_g2, F.linear(nc, W2), b2, True) for e, nc in zip(eng, new_c)]
+            got = torch.cat([F.linear(o, Wo, bo) for o in out])
+    finally:
+        ops.TILED_MIN_WORK = saved
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), atol=2e-5)
