@@ -99,36 +99,50 @@ class LocalOps:
     genes_finish: Callable     # (partial_sum_global, p_g, bias, relu)     -> h_g'
 
 
+def dropout_mask(shape, p: float, generator: Optional[torch.Generator], device, dtype=torch.float32) -> torch.Tensor:
+    """Inverted-dropout multiplier (0 or 1/(1-p)) drawn from ``generator`` - ``nn.Dropout`` (gnn.py:33-36,62-63) with an
+    explicit random stream, so that the REPLICATED gene rows get the same mask on every rank (one generator seeded
+    identically everywhere) while every rank draws its own cells' mask from a rank-local one."""
+    keep = torch.rand(shape, generator=generator, device=device) >= p
+    return keep.to(dtype) / (1.0 - p)
+
+
 def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local: torch.Tensor, ops: LocalOps,
                     n_layers: int, gather_logits: bool = True, shard_sizes: Optional[Sequence[int]] = None,
-                    async_gather: bool = False):
+                    async_gather: bool = False, dropout_masks: Optional[Sequence[Tuple[torch.Tensor, torch.Tensor]]] = None,
+                    relu: bool = True):
     """Layer-wise forward over a cell shard.  ``weights`` = list of (W_i, b_i) + (W_out, b_out) last.
     Features may be stored in fp16 (BASELINE cfg5): they are widened on the way into the fp32 projection, i.e. the
     arithmetic is "fp16-rounded inputs, fp32 accumulate".  ``shard_sizes`` (cells per rank, known at graph build)
     lets the logits concat run without a size exchange / host sync; with ``async_gather`` (equal shards only) the
     concat is left running on the communicator's stream and ``(logits_all, work)`` is returned - the caller waits on
-    ``work`` before reading, so the output collection of one batch overlaps the next batch's compute."""
+    ``work`` before reading, so the output collection of one batch overlaps the next batch's compute.
+    ``dropout_masks[i] = (mask_genes [G,D_i], mask_cells_local [C_p,D_i])``: train-mode dropout on the input rows of
+    layer i (gnn.py:60-64) - the gene mask must be identical on every rank (see :func:`dropout_mask`)."""
     h_g, h_c = feats_g, feats_c_local
     for i in range(n_layers):
         W, b = weights[i]
         last = i == n_layers - 1
+        if dropout_masks is not None:
+            m_g, m_c = dropout_masks[i]
+            h_g, h_c = h_g.to(m_g.dtype) * m_g, h_c.to(m_c.dtype) * m_c
         p_g = torch.nn.functional.linear(h_g.to(W.dtype), W)
         p_c = torch.nn.functional.linear(h_c.to(W.dtype), W)
         if last:
-            h_c = ops.cells_layer(p_g, p_c, b, True)
+            h_c = ops.cells_layer(p_g, p_c, b, relu)
             break
         part = ops.genes_partial(p_c)
         if torch.is_grad_enabled() and part.requires_grad:
-            new_c = ops.cells_layer(p_g, p_c, b, True)
+            new_c = ops.cells_layer(p_g, p_c, b, relu)
             part = all_reduce_sum(part)                 # differentiable: backward all-reduces dH1_g
         else:
             # the ONE data-path collective (X2, SURVEY 8e) runs on the communicator's stream while this rank's
             # cells<-genes pass (row-independent, no communication) computes
             work = dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=True) if world()[1] > 1 else None
-            new_c = ops.cells_layer(p_g, p_c, b, True)
+            new_c = ops.cells_layer(p_g, p_c, b, relu)
             if work is not None:
                 work.wait()                             # stream-level dependency on GPU backends, no host sync
-        h_g = ops.genes_finish(part, p_g, b, True)
+        h_g = ops.genes_finish(part, p_g, b, relu)
         h_c = new_c
     Wo, bo = weights[n_layers]
     logits = torch.nn.functional.linear(h_c, Wo, bo)
@@ -174,13 +188,14 @@ def all_reduce_grads(params) -> None:
 
 
 def sharded_train_step(params, weights_fn, feats_g, feats_c_local, labels_local, ops: LocalOps, n_layers: int,
-                       optimizer, seeds_local: Optional[torch.Tensor] = None) -> float:
+                       optimizer, seeds_local: Optional[torch.Tensor] = None, dropout_masks=None, relu: bool = True) -> float:
     """One full-batch data-parallel training step over cell shards (BASELINE cfg4).
 
     loss = CrossEntropyLoss(reduction='sum') over this rank's cells (train.py:36); because the loss is a SUM, adding
     the per-rank parameter gradients (all_reduce_grads) reproduces the single-process gradient exactly, and every rank
     then applies the identical optimizer step.  Returns the global loss."""
-    logits = sharded_forward(weights_fn(), None, feats_g, feats_c_local, ops, n_layers, gather_logits=False)
+    logits = sharded_forward(weights_fn(), None, feats_g, feats_c_local, ops, n_layers, gather_logits=False,
+                             dropout_masks=dropout_masks, relu=relu)
     if seeds_local is not None:
         logits = logits[seeds_local]
     loss = torch.nn.functional.cross_entropy(logits, labels_local, reduction="sum")

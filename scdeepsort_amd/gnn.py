@@ -44,6 +44,19 @@ class NodeUpdate(nn.Module):
         nn.init.xavier_uniform_(self.fc_neigh.weight, gain=nn.init.calculate_gain('relu'))
 
 
+def pad_width(nnz: int, H: int) -> int:
+    """Hidden width as the kernels carry it.  Large graphs run the LDS-streamed kernel, whose hand-scheduled D = 256
+    specialisation is ~2x faster per edge than the generic one at ANY narrower width (measured at cfg3: 2.6-2.8 ms for
+    D = 64..200 vs 1.3 ms at D = 256).  A narrower hidden width - e.g. the reference default hidden_dim = 200,
+    train.py:137 - is therefore carried as 256 columns with zero weights / bias in the padding (exact: the extra
+    columns stay 0 through ReLU and meet zero weight columns in the next layer).  ``nnz`` decides which kernel runs;
+    a sharded job passes the MAX over ranks so that every rank pads alike (the [G, Hp] partial sums are all-reduced)."""
+    from . import ops
+    if H < 256 and ops.TILED_MIN_WORK is not None and nnz * H >= ops.TILED_MIN_WORK:
+        return 256
+    return -(-H // 4) * 4                                  # the kernels move float4s: widths are multiples of 4
+
+
 def _is_relu(fn) -> bool:
     return fn in (F.relu, torch.relu) or isinstance(fn, nn.ReLU)
 
@@ -66,15 +79,7 @@ class GNN(nn.Module):
 
     # -- one NodeFlow block, both node types ------------------------------------------------------
     def _pad_width(self, g: CellGeneGraph, H: int) -> int:
-        """Large graphs run the LDS-streamed kernel, whose hand-scheduled D = 256 specialisation is ~2x faster per
-        edge than the generic one at ANY narrower width (measured at cfg3: 2.6-2.8 ms for D = 64..200 vs 1.3 ms at
-        D = 256).  A narrower hidden width - e.g. the reference default hidden_dim = 200, train.py:137 - is therefore
-        carried as 256 columns with zero weights / bias in the padding (exact: the extra columns stay 0 through ReLU
-        and meet zero weight columns in the next layer)."""
-        from . import ops
-        if H < 256 and ops.TILED_MIN_WORK is not None and g.cg.nnz * H >= ops.TILED_MIN_WORK:
-            return 256
-        return -(-H // 4) * 4                              # the kernels move float4s: widths are multiples of 4
+        return pad_width(g.cg.nnz, H)
 
     def _layer(self, g: CellGeneGraph, layer: NodeUpdate, h_g: torch.Tensor, h_c: torch.Tensor,
                want_genes: bool, cell_rows: Optional[torch.Tensor]):

@@ -13,15 +13,32 @@ import torch.nn.functional as F
 
 from . import dist as D
 from ._lib import DST_IS_GENE, NO_ALPHA, SRC_IS_GENE
-from .gnn import GNN
+from .gnn import GNN, _is_relu, pad_width
 from .graph import AggCsr, CellGeneGraph, _normalize_on_device, build_plan
 from .ops import agg_fwd, weighted_mean_aggregate, weighted_sum
 
 
 class ShardedWgnn:
-    def __init__(self, model: GNN, graph: CellGeneGraph, world: int, shard_sizes=None):
+    def __init__(self, model: GNN, graph: CellGeneGraph, world: int, shard_sizes=None, pad_nnz: Optional[int] = None,
+                 seed: int = 0):
         self.model, self.graph, self.world = model, graph, world
         self.shard_sizes = shard_sizes          # cells per rank (exchanged once at build): sync-free logits concat
+        # the zero-padding of narrow hidden widths must not depend on the LOCAL shard size: the [G, Hp] partial sums and
+        # the flat gradient bucket are all-reduced, so every rank must carry the same Hp.  ``pad_nnz`` = max over ranks.
+        self.pad_nnz = graph.cg.nnz if pad_nnz is None else int(pad_nnz)
+        for l in model.layers:
+            if l.norm is not None or not (l.activation is None or _is_relu(l.activation)):
+                raise ValueError("the sharded path fuses ReLU into the aggregation epilogue: norm / non-ReLU "
+                                 "activations are not supported here (the reference never passes them, train.py:26-32)")
+        self.relu = all(l.activation is not None for l in model.layers)
+        if not self.relu and any(l.activation is not None for l in model.layers):
+            raise ValueError("mixed per-layer activations are not supported on the sharded path")
+        # train-mode dropout (gnn.py:33-36,60-64): replicated gene rows need the SAME mask on every rank -> one stream
+        # seeded identically everywhere; every rank's own cells draw from a rank-local stream
+        rank = D.world()[0]
+        dev = graph.device
+        self._gen_shared = torch.Generator(device=dev).manual_seed(1_000_003 * (seed + 1))
+        self._gen_local = torch.Generator(device=dev).manual_seed(1_000_003 * (seed + 1) + 7919 * (rank + 1))
 
     @property
     def nnz(self) -> int:
@@ -37,7 +54,7 @@ class ShardedWgnn:
 
     @staticmethod
     def build(model: GNN, rowptr: torch.Tensor, col: torch.Tensor, raw: torch.Tensor, num_genes: int,
-              chunk: Optional[int] = None, global_stats=None) -> "ShardedWgnn":
+              chunk: Optional[int] = None, global_stats=None, seed: int = 0) -> "ShardedWgnn":
         """``rowptr/col/raw``: device CSR of THIS rank's (cells x genes) raw expression.
         ``global_stats`` = (deg, sum) over ALL shards; when None and a process group is up they are all-reduced."""
         rank, world = D.world()
@@ -57,14 +74,23 @@ class ShardedWgnn:
             gc._t = None
             gc._tile_plan = None
             world = max(world, 2)
-        sizes = None
+        sizes, pad_nnz = None, None
         if D.world()[1] > 1:
             import torch.distributed as tdist
-            mine = torch.tensor([g.num_cells], dtype=torch.long, device=col.device)
+            mine = torch.tensor([g.num_cells, g.cg.nnz], dtype=torch.long, device=col.device)
             every = [torch.zeros_like(mine) for _ in range(D.world()[1])]
             tdist.all_gather(every, mine)
-            sizes = [int(t.item()) for t in every]
-        return ShardedWgnn(model, g, world, sizes)
+            sizes = [int(t[0].item()) for t in every]
+            pad_nnz = max(int(t[1].item()) for t in every)          # rank-invariant width decision (see __init__)
+        eng = ShardedWgnn(model, g, world, sizes, pad_nnz, seed)
+        if D.world()[1] > 1:                                        # one-time check: equal carried widths on every rank
+            import torch.distributed as tdist
+            w = torch.tensor([W.shape[0] for W, _ in eng._weights()[:-1]], dtype=torch.long, device=col.device)
+            every = [torch.zeros_like(w) for _ in range(D.world()[1])]
+            tdist.all_gather(every, w)
+            if any(not torch.equal(e, w) for e in every):
+                raise RuntimeError(f"ranks disagree on the carried hidden widths: {[e.tolist() for e in every]}")
+        return eng
 
     # -- local arithmetic bound to the HIP kernels (differentiable: K1 forward, K2/K3 backward) ---------
     def _ops(self) -> D.LocalOps:
@@ -108,7 +134,7 @@ class ShardedWgnn:
             W, b = l.fc_neigh.weight, l.fc_neigh.bias
             if width_in is not None and width_in > W.shape[1]:
                 W = F.pad(W, (0, width_in - W.shape[1]))
-            Hp = m._pad_width(self.graph, W.shape[0])
+            Hp = pad_width(self.pad_nnz, W.shape[0])
             if Hp != W.shape[0]:
                 W, b = F.pad(W, (0, 0, 0, Hp - W.shape[0])), F.pad(b, (0, Hp - b.shape[0]))
             out.append((W, b))
@@ -118,11 +144,24 @@ class ShardedWgnn:
             Wo = F.pad(Wo, (0, width_in - Wo.shape[1]))
         return out + [(Wo, m.linear.bias)]
 
-    def train_step(self, feats_g, feats_c_local, labels_local, optimizer, seeds_local=None) -> float:
-        """Data-parallel full-batch step (cfg4): local CE-sum loss, SUM all-reduce of gradients, identical Adam step."""
+    def dropout_masks(self, feats_g, feats_c_local):
+        """Per-layer (gene mask, local cell mask) of one train-mode forward, or None (eval / dropout = 0)."""
+        m = self.model
+        if m.dropout is None or not m.training:
+            return None
+        p, dev = float(m.dropout.p), feats_g.device
+        widths = [feats_g.shape[1]] + [W.shape[0] for W, _ in self._weights()[:-1]][: m.n_layers - 1]
+        return [(D.dropout_mask((feats_g.shape[0], w), p, self._gen_shared, dev),
+                 D.dropout_mask((feats_c_local.shape[0], w), p, self._gen_local, dev)) for w in widths]
+
+    def train_step(self, feats_g, feats_c_local, labels_local, optimizer, seeds_local=None, dropout_masks=None) -> float:
+        """Data-parallel full-batch step (cfg4): local CE-sum loss, SUM all-reduce of gradients, identical Adam step.
+        Dropout (train.py:26-32 passes ``dropout`` into GNN) is applied to every layer's input rows like gnn.py:60-64."""
         self.model.train()
+        if dropout_masks is None:
+            dropout_masks = self.dropout_masks(feats_g, feats_c_local)
         return D.sharded_train_step(list(self.model.parameters()), self._weights, feats_g, feats_c_local, labels_local,
-                                    self._ops(), self.model.n_layers, optimizer, seeds_local)
+                                    self._ops(), self.model.n_layers, optimizer, seeds_local, dropout_masks, self.relu)
 
     def forward(self, feats_g: torch.Tensor, feats_c_local: torch.Tensor, gather_logits: bool = True,
                 async_gather: bool = False) -> torch.Tensor:
@@ -134,7 +173,7 @@ class ShardedWgnn:
             return m.linear(m.embed(self.graph, (feats_g, feats_c_local)))
         self.wait_gather()
         res = D.sharded_forward(self._weights(), None, feats_g, feats_c_local, self._ops(), m.n_layers, gather_logits,
-                                self.shard_sizes, async_gather)
+                                self.shard_sizes, async_gather, self.dropout_masks(feats_g, feats_c_local), self.relu)
         if async_gather:
             res, self._pending = res
         return res

@@ -97,9 +97,19 @@ class NodeFlowStandIn:
                        {"weight": torch.from_numpy(w)})
         m = message_func(batch)[msg]
         n_dst = len(self.layer_nids[i + 1])
-        total = torch.zeros(n_dst, m.shape[1], dtype=m.dtype).index_add_(0, d, m)
-        deg = torch.zeros(n_dst, dtype=m.dtype).index_add_(0, d, torch.ones(len(d), dtype=m.dtype))
-        self.layers[i + 1].data[out] = total / deg.unsqueeze(-1)
+        # fn.mean, written as its definition: one destination at a time, its mailbox = the messages on its in-edges,
+        # summed in float64 in edge order and divided by their number.  Deliberately shares no code shape with
+        # oracle/wgnn_oracle.py::block_compute (index_add_ + degree vector) so that the two are independent.
+        mailbox = [[] for _ in range(n_dst)]
+        for e, v in enumerate(e_dst.tolist()):
+            mailbox[v].append(e)
+        rows = []
+        for v in range(n_dst):
+            acc = torch.zeros(m.shape[1], dtype=torch.float64)
+            for e in mailbox[v]:
+                acc = acc + m[e].double()
+            rows.append((acc / float(len(mailbox[v]))).to(m.dtype))
+        self.layers[i + 1].data[out] = torch.stack(rows)
         self.layers[i + 1].data.update(apply_func(self.layers[i + 1]))
 
 

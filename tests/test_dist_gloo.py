@@ -84,6 +84,24 @@ def _worker(rank, world, port, out_dir, cells=90):
         l3ref = D.sharded_forward(weights, None, f16[:G].double(), f16[G + lo:G + hi].double(), ops, 2, True, sizes)
         assert torch.equal(l3, l3ref)
 
+        # ---- train-mode dropout on every layer's input rows (gnn.py:60-64): fixed masks, the gene mask replicated
+        rgd = O.build_reference_graph(c["expr"])
+        gm = torch.Generator().manual_seed(77)
+        masks = [(torch.rand(G + C, w, generator=gm) >= 0.3).double() / 0.7 for w in (12, 8)]
+        ld = D.sharded_forward(weights, None, feats[:G], feats[G + lo:G + hi], ops, 2, True, sizes,
+                               dropout_masks=[(m[:G], m[G + lo:G + hi]) for m in masks])
+        want_d = O.nodeflow_forward({k: v.double() for k, v in sd.items()}, rgd, feats, np.arange(G, G + C), 2,
+                                    dropout_masks=masks)
+        np.testing.assert_allclose(ld.numpy(), want_d.numpy(), atol=1e-5)
+        assert not np.allclose(ld.numpy(), logits.numpy(), atol=1e-3)          # the masks did something
+        # the shared stream gives every rank the same gene mask, the local stream differs per rank
+        g_sh = torch.Generator().manual_seed(5); g_lo = torch.Generator().manual_seed(6 + rank)
+        mg = D.dropout_mask((G, 4), 0.5, g_sh, "cpu"); mc = D.dropout_mask((3, 4), 0.5, g_lo, "cpu")
+        both = [torch.zeros_like(mg) for _ in range(world)]
+        dist.all_gather(both, mg)
+        assert all(torch.equal(b, mg) for b in both)
+        assert set(mg.unique().tolist()) <= {0.0, 2.0}
+
         # ---- data-parallel training step (cfg4): grads after SUM all-reduce == single-process autograd grads
         labels = torch.from_numpy(np.random.default_rng(5).integers(0, 3, C))
         params = {k: torch.nn.Parameter(v.clone()) for k, v in sd.items()}

@@ -804,3 +804,41 @@ def test_sharded_engine_carries_narrow_hidden_padded():
     finally:
         ops.TILED_MIN_WORK = saved
     np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), atol=2e-5)
+
+
+def test_kat_two_layers_predict_graph_exact_rational_on_gpu():
+    """The exact-rational known answer (tests/golden/make_kat_rational.py: D = 4, two layers, hub gene, a test cell and a
+    gene fed by nobody) through the HIP path, both multiply orders, plus the layer-1 activations of every node."""
+    from test_oracle import _kat_rational
+    kat, sd, expr, support, feats = _kat_rational()
+    G = kat["genes"]
+    g = sda.CellGeneGraph.from_expression(expr, support, device=DEV)
+    np.testing.assert_allclose(g.cg.val.cpu().numpy()[-3:], [2 / 3, 2 / 3, 5 / 3], rtol=1e-6)       # into the test cell
+    assert g.gc.nnz == 5 and int(g.gc.rowptr[3] - g.gc.rowptr[2]) == 0                               # g2: no in-edge
+    for order in ("project_first", "aggregate_first"):
+        m = make_model({k: v.float() for k, v in sd.items()}, 4, 4, 2, 2, G, order)
+        with torch.no_grad():
+            x = dev(feats)
+            h_g, h_c = m._layer(g, m.layers[0], x[:G], x[G:], want_genes=True, cell_rows=None)
+            logits = m(g, x)
+        np.testing.assert_allclose(torch.cat([h_g, h_c]).cpu().numpy(), kat["h1"], atol=2e-6)
+        np.testing.assert_allclose(logits.cpu().numpy(), kat["logits"], atol=5e-6)
+
+
+@pytest.mark.parametrize("unsure_rate", [0.0, 2.0, 3.0])
+def test_api_classify_on_gpu_matches_oracle_postprocess(unsure_rate):
+    """a10 (predict.py:78-88) on device logits produced by the HIP forward."""
+    from scdeepsort_amd.api import _classify
+    c = small_case(seed=9)
+    sd = O.init_params(c["dim"], c["hidden"], c["n_classes"], 2, c["G"], seed=4)
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
+    m = make_model(sd, c["dim"], c["hidden"], c["n_classes"], 2, c["G"])
+    with torch.no_grad():
+        logits = m(g, dev(c["feats"])) * 3.0
+    pred, prob = _classify(logits, unsure_rate)
+    want, wprob = O.postprocess(logits.cpu().numpy(), unsure_rate)
+    np.testing.assert_allclose(prob, wprob, atol=1e-6)
+    clear = np.abs(wprob.max(1) - unsure_rate / c["n_classes"]) > 1e-6
+    np.testing.assert_array_equal(pred[clear], want[clear])
+    if unsure_rate == 3.0:
+        assert (pred == -1).any() and (pred >= 0).any()

@@ -210,3 +210,64 @@ def test_gradient_oracle_matches_executed_reference_code(name):
     assert abs(float(loss) - float(z["loss"])) < 1e-5 * max(1.0, abs(float(z["loss"])))
     for k, gval in grads.items():
         np.testing.assert_allclose(gval.numpy(), z["grad." + k], atol=3e-6, rtol=1e-5, err_msg=k)
+
+
+def _kat_rational():
+    import json
+    kat = json.loads((GOLDEN / "kat_2layer_predict.json").read_text())
+    t = lambda x: torch.tensor(x, dtype=torch.float64)
+    sd = {"layers.0.fc_neigh.weight": t(kat["W1"]), "layers.0.fc_neigh.bias": t(kat["b1"]),
+          "layers.1.fc_neigh.weight": t(kat["W2"]), "layers.1.fc_neigh.bias": t(kat["b2"]),
+          "alpha": t(kat["alpha"]).reshape(-1, 1), "linear.weight": t(kat["W_out"]), "linear.bias": t(kat["b_out"])}
+    expr = sp.csr_matrix(np.array(kat["expr_rows"], dtype=np.float32))
+    return kat, sd, expr, np.array(kat["support_mask"], bool), np.array(kat["features"], np.float32)
+
+
+def test_kat_two_layers_predict_graph_exact_rational():
+    """D = 4, two layers, a hub gene, a test cell (gene->cell edges only) and a gene whose only expressing cell is that
+    test cell: answers derived in exact rational arithmetic from the cited reference lines
+    (tests/golden/make_kat_rational.py) - independent of numpy/torch and of the DGL stand-in."""
+    kat, sd, expr, support, feats = _kat_rational()
+    G, C = kat["genes"], kat["cells"]
+    for dt, tol in ((np.float64, 5e-7), (np.float32, 2e-6)):      # graph weights are normalised in fp32 like the reference
+        sdd = {k: v if dt == np.float64 else v.float() for k, v in sd.items()}
+        logits, hidden = O.csr_forward(sdd, O.build_csr_graph(expr, support, dtype=dt), feats.astype(dt), 2, dtype=dt,
+                                       return_hidden=True)
+        np.testing.assert_allclose(logits, kat["logits"], atol=tol * 10, rtol=tol)
+        np.testing.assert_allclose(np.concatenate([hidden[0][0], hidden[0][1]]), kat["h1"], atol=tol * 10, rtol=tol)
+    rg = O.build_reference_graph(expr, support)
+    got = O.nodeflow_forward({k: v.double() for k, v in sd.items()}, rg, torch.from_numpy(feats).double(),
+                             np.arange(G, G + C), 2)
+    np.testing.assert_allclose(got.numpy(), kat["logits"], atol=2e-6)      # fp32-normalised weights in the edge list
+    # the gene expressed only by the test cell has no in-edge: its layer-1 row is its self-loop alone
+    a, x = kat["alpha"], np.array(kat["features"][2])
+    want = np.maximum(np.array(kat["W1"]) @ (a[G] * x) + np.array(kat["b1"]), 0)
+    np.testing.assert_allclose(kat["h1"][2], want, atol=1e-12)
+    # normalised weights as on paper: into c3 (3 in-edges 2,2,5 -> 3*x/9), into g0 (support cells 1,2,4 -> 3*x/7)
+    nw = kat["normalised_weights_exact"]
+    assert (nw["g0->c3"], nw["g2->c3"], nw["c0->g0"], nw["c2->g0"]) == ("2/3", "5/3", "3/7", "12/7")
+    assert "c3->g0" not in nw and "c3->g2" not in nw
+
+
+@pytest.mark.parametrize("unsure_rate", [0.0, 2.0, 3.0])
+def test_api_classify_matches_oracle_postprocess(unsure_rate):
+    """a10 (predict.py:78-88): softmax, 'unsure' iff max_prob < unsure_rate/num_classes (STRICT), else argmax -
+    product ``api._classify`` against the restatement, including rows that sit exactly on the boundary."""
+    from scdeepsort_amd.api import _classify
+    rng = np.random.default_rng(3)
+    logits = rng.normal(0, 1.5, (500, 4)).astype(np.float32)
+    logits[0] = 0.0                                        # uniform: max_prob = 1/4 exactly
+    logits[1] = [np.log(3.0), 0.0, 0.0, 0.0]               # max_prob = 3/6 = 0.5 = 2/4 (up to fp32 rounding)
+    logits[2] = [5.0, 5.0, -5.0, -5.0]                     # tie: argmax takes the first
+    pred, prob = _classify(torch.from_numpy(logits), unsure_rate)
+    want, wprob = O.postprocess(logits, unsure_rate)
+    np.testing.assert_allclose(prob, wprob, atol=1e-6)
+    # rows whose max prob is within rounding of the threshold may legitimately fall either way; everything else is exact
+    clear = np.abs(wprob.max(1) - unsure_rate / 4) > 1e-6
+    assert clear.sum() >= 497
+    np.testing.assert_array_equal(pred[clear], want[clear])
+    if unsure_rate == 0.0:
+        assert (pred >= 0).all()
+    if unsure_rate == 3.0:
+        assert (pred == -1).sum() > 100 and pred[0] == -1
+    assert pred[2] in (0, -1) and (pred[2] == want[2])
