@@ -68,6 +68,10 @@ def cpu_baseline(graph, model, feats_g, feats_c, gpu_logits, cfg):
     every.append({"name": "port_c_openmp", "value": round(C / t, 1), "unit": "cells/s", "cores": CO.num_threads(),
                   "s_per_forward": round(t, 3), "sample": f"full {cfg.name} graph, best of {reps}; C/OpenMP aggregation "
                   "(reference multiply order, aggregate-first) + torch Linear", "max_abs_err_vs_gpu": err})
+    t, reps, l1 = best_of(lambda: CO.forward(sd, ocg, feats, model.n_layers, order="project_first"), 3, 8.0)
+    every.append({"name": "port_c_openmp_project_first", "value": round(C / t, 1), "unit": "cells/s", "cores": CO.num_threads(),
+                  "s_per_forward": round(t, 3), "sample": f"full {cfg.name} graph, best of {reps}; C/OpenMP aggregation of the "
+                  "projected H-wide rows (the GPU path's order) + torch Linear", "max_abs_err_vs_gpu": float(np.abs(l1 - gpu).max())})
     t, reps, l2 = best_of(lambda: CB.b2_torch_csr_forward(sd, ocg, feats, model.n_layers), 3, 10.0)
     every.append({"name": "B2_torch_csr_spmm", "value": round(C / t, 1), "unit": "cells/s", "cores": threads,
                   "s_per_forward": round(t, 3), "sample": f"full {cfg.name} graph, best of {reps}; torch.sparse CSR SpMM + "

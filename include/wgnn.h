@@ -20,7 +20,10 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
  *   - functions enqueue work on `stream` and return immediately: they never
  *     synchronise, never allocate persistent memory, never throw; they are
- *     re-entrant across streams (scratch is passed in by the caller);
+ *     re-entrant across streams, threads and devices (scratch is passed in by
+ *     the caller; the only library state - "dynamic-LDS limit already raised"
+ *     marks - is kept per device in atomics).  The CURRENT device
+ *     (hipGetDevice) must be the one that owns `stream` and the pointers;
  *   - return value: 0 = ok, negative = WGNN_ERR_* (see wgnn_last_error_string);
  *   - CSR is destination-major: row r lists the in-edges of destination r,
  *     `col` = source index, `val` = normalised edge weight.  Self-loops are
@@ -91,6 +94,15 @@ int wgnn_plan_build_host(const int32_t* rowptr_host, const int32_t* row_ids_host
                          int32_t chunk_nnz,
                          int32_t* items_host, int32_t* long_host,
                          int64_t* n_items, int64_t* n_long, int64_t* n_partials);
+
+/* Same, from a 64-bit row-pointer array (scipy / torch CSR of large matrices).  The kernels address non-zeros with
+ * 32-bit offsets (items hold {begin, end} as int32; col/val of 2^31 edges would be 17 GB per direction): when
+ * rowptr_host[r+1] > INT32_MAX for any planned row this returns WGNN_ERR_UNSUPPORTED - the caller shards the cell
+ * axis (one CSR per GPU / per shard) so that every shard stays below 2^31 non-zeros. */
+int wgnn_plan_build_host_i64(const int64_t* rowptr_host, const int32_t* row_ids_host, int64_t n_rows,
+                             int32_t chunk_nnz,
+                             int32_t* items_host, int32_t* long_host,
+                             int64_t* n_items, int64_t* n_long, int64_t* n_partials);
 
 /* ---------------------------------------------------------------------------
  * K1  forward:  replaces message_func + fn.mean (+ optional bias/ReLU epilogue)

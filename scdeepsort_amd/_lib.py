@@ -23,6 +23,7 @@ SIGNATURES = {
     "wgnn_last_error_string": (C.c_char_p, [C.c_int]),
     "wgnn_agg_workspace_bytes": (C.c_int, [_i64, _i64, _i32, _int, _int, _vp, _vp]),
     "wgnn_plan_build_host": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "wgnn_plan_build_host_i64": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "wgnn_agg_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _int, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
                                _vp, _i64, _i64, _i32, _int, _int, _u32,
                                _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
@@ -57,6 +58,15 @@ def lib() -> C.CDLL:
         fn = getattr(dll, name)          # AttributeError here = header/ABI drift
         fn.restype, fn.argtypes = res, args
     return dll
+
+
+def call(device, name: str, *args) -> int:
+    """Invoke a kernel-launching entry point with ``device`` current: the library launches on the stream it is given and
+    keeps per-device kernel attributes keyed by hipGetDevice(), so the caller's current device must be the one that owns
+    the tensors / stream (matters as soon as a process drives more than one GPU or gpu_id != 0)."""
+    import torch
+    with torch.cuda.device(device):
+        return getattr(lib(), name)(*args)
 
 
 def check(rc: int, what: str) -> None:

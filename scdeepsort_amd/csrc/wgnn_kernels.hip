@@ -19,6 +19,7 @@
 // scratch and are folded in a fixed order by a finalize kernel (deterministic,
 // no atomics).
 
+#include <limits.h>
 #include "wgnn_common.h"
 
 namespace {
@@ -196,6 +197,40 @@ int launch_finalize_f32(const KArgs& a, int epi, hipStream_t st) {
 }
 }  // namespace wgnn
 
+template <typename TPtr>
+static int plan_build(const TPtr* rowptr, const int32_t* row_ids, int64_t n_rows, int32_t chunk,
+                      int32_t* items, int32_t* long_rows, int64_t* n_items, int64_t* n_long, int64_t* n_partials) {
+    if (!rowptr || n_rows < 0 || chunk <= 0 || !n_items || !n_long || !n_partials) return WGNN_ERR_BAD_ARG;
+    int64_t ni = 0, nl = 0, np = 0;
+    for (int64_t i = 0; i < n_rows; ++i) {
+        const int64_t r = row_ids ? row_ids[i] : i;
+        const int64_t b64 = rowptr[r], e64 = rowptr[r + 1];
+        if (e64 < b64 || b64 < 0) return WGNN_ERR_PLAN;
+        if (e64 > INT32_MAX) return WGNN_ERR_UNSUPPORTED;         // 32-bit nnz offsets in items / kernels: shard the cell axis
+        const int32_t b = (int32_t)b64, e = (int32_t)e64;
+        const int32_t nnz = e - b;
+        if (nnz <= chunk) {
+            if (items) { int32_t* it = items + 4 * ni; it[0] = (int32_t)i; it[1] = b; it[2] = e; it[3] = -1; }
+            ++ni;
+        } else {
+            const int32_t nc = (nnz + chunk - 1) / chunk;
+            if (long_rows) { int32_t* lr = long_rows + 4 * nl; lr[0] = (int32_t)i; lr[1] = (int32_t)np; lr[2] = nc; lr[3] = 0; }
+            for (int32_t c = 0; c < nc; ++c) {
+                if (items) {
+                    int32_t* it = items + 4 * ni;
+                    const int64_t ce = (int64_t)b + (int64_t)(c + 1) * chunk;
+                    it[0] = (int32_t)i; it[1] = b + c * chunk; it[2] = ce < e ? (int32_t)ce : e;
+                    it[3] = (int32_t)(np + c);
+                }
+                ++ni;
+            }
+            np += nc; ++nl;
+        }
+    }
+    *n_items = ni; *n_long = nl; *n_partials = np;
+    return WGNN_OK;
+}
+
 extern "C" {
 
 int wgnn_version(void) { return WGNN_VERSION; }
@@ -215,7 +250,7 @@ const char* wgnn_last_error_string(int code) {
         case WGNN_OK: return "ok";
         case WGNN_ERR_BAD_ARG: return "bad argument (null pointer, negative size or bad enum)";
         case WGNN_ERR_ALIGNMENT: return "D / leading dimension not a multiple of 4 or pointer not 16-byte aligned";
-        case WGNN_ERR_UNSUPPORTED: return "unsupported dtype or feature width (D <= 1024 required)";
+        case WGNN_ERR_UNSUPPORTED: return "unsupported dtype, feature width (D <= 1024 required) or nnz >= 2^31 (shard the cell axis)";
         case WGNN_ERR_WORKSPACE: return "workspace (partials) too small or missing";
         case WGNN_ERR_LAUNCH: return "HIP launch failed";
         case WGNN_ERR_PLAN: return "plan malformed";
@@ -225,32 +260,12 @@ const char* wgnn_last_error_string(int code) {
 
 int wgnn_plan_build_host(const int32_t* rowptr, const int32_t* row_ids, int64_t n_rows, int32_t chunk,
                          int32_t* items, int32_t* long_rows, int64_t* n_items, int64_t* n_long, int64_t* n_partials) {
-    if (!rowptr || n_rows < 0 || chunk <= 0 || !n_items || !n_long || !n_partials) return WGNN_ERR_BAD_ARG;
-    int64_t ni = 0, nl = 0, np = 0;
-    for (int64_t i = 0; i < n_rows; ++i) {
-        const int64_t r = row_ids ? row_ids[i] : i;
-        const int32_t b = rowptr[r], e = rowptr[r + 1];
-        if (e < b) return WGNN_ERR_PLAN;
-        const int32_t nnz = e - b;
-        if (nnz <= chunk) {
-            if (items) { int32_t* it = items + 4 * ni; it[0] = (int32_t)i; it[1] = b; it[2] = e; it[3] = -1; }
-            ++ni;
-        } else {
-            const int32_t nc = (nnz + chunk - 1) / chunk;
-            if (long_rows) { int32_t* lr = long_rows + 4 * nl; lr[0] = (int32_t)i; lr[1] = (int32_t)np; lr[2] = nc; lr[3] = 0; }
-            for (int32_t c = 0; c < nc; ++c) {
-                if (items) {
-                    int32_t* it = items + 4 * ni;
-                    it[0] = (int32_t)i; it[1] = b + c * chunk; it[2] = (b + (c + 1) * chunk < e) ? b + (c + 1) * chunk : e;
-                    it[3] = (int32_t)(np + c);
-                }
-                ++ni;
-            }
-            np += nc; ++nl;
-        }
-    }
-    *n_items = ni; *n_long = nl; *n_partials = np;
-    return WGNN_OK;
+    return plan_build(rowptr, row_ids, n_rows, chunk, items, long_rows, n_items, n_long, n_partials);
+}
+
+int wgnn_plan_build_host_i64(const int64_t* rowptr, const int32_t* row_ids, int64_t n_rows, int32_t chunk,
+                             int32_t* items, int32_t* long_rows, int64_t* n_items, int64_t* n_long, int64_t* n_partials) {
+    return plan_build(rowptr, row_ids, n_rows, chunk, items, long_rows, n_items, n_long, n_partials);
 }
 
 static int check_common(int32_t D, int64_t n, const void* items, int64_t n_items, const void* long_rows,

@@ -22,6 +22,7 @@
 //
 // Two kernels: agg_tiled (any D <= 256: per-row ballot visits, compiler-scheduled) and
 // agg_tiled_flat4 (D == 256: generated straight-line ISA, see below and gen_flat_asm.py).
+#include <atomic>
 #include <type_traits>
 #include "wgnn_common.h"
 #include "wgnn_flat_asm.inc"
@@ -358,32 +359,37 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
     }
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE property of a kernel: the "already raised to" mark is kept
+// per device (the current one - the caller's stream must belong to it) in atomics, so that one process may drive several
+// GPUs from several threads.  Two threads racing on the same device at worst both set the (idempotent) attribute.
+constexpr int kMaxDevices = 64;
+struct LdsMarks { std::atomic<int> v[kMaxDevices]; };
+
+inline int raise_lds_limit(LdsMarks& marks, const void* fn, int lds) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return WGNN_ERR_LAUNCH;
+    if (marks.v[dev].load(std::memory_order_acquire) >= lds) return WGNN_OK;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return WGNN_ERR_LAUNCH;
+    int seen = marks.v[dev].load(std::memory_order_relaxed);
+    while (seen < lds && !marks.v[dev].compare_exchange_weak(seen, lds, std::memory_order_release)) {}
+    return WGNN_OK;
+}
+
 template <typename TOut, int EPI>
 int launch_tiled(const KArgs& a, const TArgs& t, long n_tiles, hipStream_t st) {
     const int lds = 2 * t.kb * a.D * (int)sizeof(float) + (a.D == 256 ? kWStripBytes : 0);
-    static int configured = 0;                       // per instantiation
-    if (configured < lds) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_tiled<TOut, EPI>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return WGNN_ERR_LAUNCH;
-        configured = lds;
-    }
     if (lds > 160 * 1024) return WGNN_ERR_PLAN;
+    static LdsMarks generic_marks{}, flat_marks{}, flat_dbg_marks{};      // per instantiation, per device
     if (a.D == 256 && !(a.flags & (1u << 19))) {       // bit 19: force the generic (row-visit) kernel, for A/B timing
-        static int flat_configured = 0;
-        if (flat_configured < lds) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_tiled_flat4<TOut, EPI, false>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(&agg_tiled_flat4<TOut, EPI, true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-                return WGNN_ERR_LAUNCH;
-            flat_configured = lds;
-        }
+        if (int rc = raise_lds_limit(flat_marks, reinterpret_cast<const void*>(&agg_tiled_flat4<TOut, EPI, false>), lds)) return rc;
+        if (a.flags & 0xFFFF0000u)
+            if (int rc = raise_lds_limit(flat_dbg_marks, reinterpret_cast<const void*>(&agg_tiled_flat4<TOut, EPI, true>), lds)) return rc;
         if (a.flags & 0xFFFF0000u)                       // timing-experiment switches: the instantiation that reads them
             hipLaunchKernelGGL((agg_tiled_flat4<TOut, EPI, true>), dim3((unsigned)n_tiles), dim3(kTW * 64), lds, st, a, t);
         else
             hipLaunchKernelGGL((agg_tiled_flat4<TOut, EPI, false>), dim3((unsigned)n_tiles), dim3(kTW * 64), lds, st, a, t);
     } else {
+        if (int rc = raise_lds_limit(generic_marks, reinterpret_cast<const void*>(&agg_tiled<TOut, EPI>), lds)) return rc;
         hipLaunchKernelGGL((agg_tiled<TOut, EPI>), dim3((unsigned)n_tiles), dim3(kTW * 64), lds, st, a, t);
     }
     return hipGetLastError() == hipSuccess ? WGNN_OK : WGNN_ERR_LAUNCH;

@@ -171,8 +171,8 @@ def _normalize_on_device(rowptr: torch.Tensor, raw: torch.Tensor) -> Tuple[torch
     n_rows = rowptr.shape[0] - 1
     out = torch.empty_like(raw)
     inv_deg = torch.empty(n_rows, dtype=torch.float32, device=raw.device)
-    _lib.check(_lib.lib().wgnn_normalize_rows(_ptr(rowptr), _ptr(raw), _ptr(out), _ptr(inv_deg), n_rows,
-                                              _stream(raw.device)), "wgnn_normalize_rows")
+    _lib.check(_lib.call(raw.device, "wgnn_normalize_rows", _ptr(rowptr), _ptr(raw), _ptr(out), _ptr(inv_deg), n_rows,
+                         _stream(raw.device)), "wgnn_normalize_rows")
     return out, inv_deg
 
 

@@ -99,7 +99,7 @@ def agg_fwd(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, self_idx: int
     if PROFILE is not None:
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record(torch.cuda.current_stream(dev))
-    rc = _lib.lib().wgnn_agg_fwd(
+    rc = _lib.call(dev, "wgnn_agg_fwd",
         _ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), _ptr(alpha), mode, self_idx,
         _ptr(h_src), h_src.stride(0), _ptr(h_self), h_self.stride(0) if h_self is not None else 0,
         _ptr(ids), _ptr(csr.inv_deg), _ptr(bias), _ptr(out), out.stride(0), n_out, D,
@@ -143,7 +143,7 @@ def agg_bwd_src(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, g: torch.
         scratch = torch.empty_like(g)
         part = torch.empty(tp.n_partials * D, dtype=torch.float32, device=dev) if tp.n_partials else None
         n_long = tp.long_rows.shape[0]
-        rc = _lib.lib().wgnn_agg_bwd_src_tiled(
+        rc = _lib.call(dev, "wgnn_agg_bwd_src_tiled",
             _ptr(alpha), mode, _ptr(scale.contiguous()), _ptr(g), g.shape[0], _ptr(scratch),
             _ptr(h_src), h_src.stride(0) if h_src is not None else 0, _ptr(dh_src), dh_src.stride(0), _ptr(dalpha),
             int(accumulate), t.n_rows, D, _ptr(tp.entries), _ptr(tp.seg_ptr), tp.nblk_max, tp.block_rows,
@@ -152,7 +152,7 @@ def agg_bwd_src(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, g: torch.
         _lib.check(rc, "wgnn_agg_bwd_src_tiled")
         return dh_src
     part = _partials(t.plan, D, dev)
-    rc = _lib.lib().wgnn_agg_bwd_src(
+    rc = _lib.call(dev, "wgnn_agg_bwd_src",
         _ptr(t.rowptr), _ptr(t.col), _ptr(t.val), _ptr(alpha), mode, _ptr(inv_deg),
         _ptr(g), g.stride(0), _ptr(h_src), h_src.stride(0) if h_src is not None else 0,
         _ptr(dh_src), dh_src.stride(0), _ptr(dalpha), int(accumulate), t.n_rows, D,
@@ -182,7 +182,7 @@ def agg_bwd_alpha(csr: AggCsr, g: torch.Tensor, h_src: torch.Tensor, h_self: Opt
         h_src = h_src.contiguous()
         part = torch.empty(tp.n_partials * D, dtype=torch.float32, device=dev) if tp.n_partials else None
         n_long = tp.long_rows.shape[0]
-        rc = _lib.lib().wgnn_agg_bwd_alpha_tiled(
+        rc = _lib.call(dev, "wgnn_agg_bwd_alpha_tiled",
             _ptr(csr.inv_deg), _ptr(g), g.stride(0), _ptr(h_src), _ptr(h_self),
             h_self.stride(0) if h_self is not None else 0, _ptr(d_row), _ptr(d_self), n_out, D,
             _ptr(tp.entries), _ptr(tp.seg_ptr), tp.nblk_max, tp.block_rows, _ptr(tp.items), _ptr(tp.hdr), tp.n_tiles,
@@ -190,7 +190,7 @@ def agg_bwd_alpha(csr: AggCsr, g: torch.Tensor, h_src: torch.Tensor, h_self: Opt
         _lib.check(rc, "wgnn_agg_bwd_alpha_tiled")
         return d_row, d_self
     part = _partials(plan, D, dev)
-    rc = _lib.lib().wgnn_agg_bwd_alpha(
+    rc = _lib.call(dev, "wgnn_agg_bwd_alpha",
         _ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), _ptr(csr.inv_deg), _ptr(ids),
         _ptr(g), g.stride(0), _ptr(h_src), h_src.stride(0), _ptr(h_self), h_self.stride(0) if h_self is not None else 0,
         _ptr(d_row), _ptr(d_self), n_out, D, _lib.FLAG_SELF_COMPACT if self_compact else 0,
@@ -233,7 +233,7 @@ def agg_fwd_tiled(csr: AggCsr, tplan, alpha: Optional[torch.Tensor], mode: int, 
         ev[0].record(torch.cuda.current_stream(dev))
     n_long = tplan.long_rows.shape[0]
     scratch = torch.empty_like(h_src) if mode == SRC_IS_GENE else None
-    rc = _lib.lib().wgnn_agg_fwd_tiled(
+    rc = _lib.call(dev, "wgnn_agg_fwd_tiled",
         _ptr(csr.rowptr), _ptr(alpha), mode, self_idx,
         _ptr(h_src), h_src.shape[0], _ptr(scratch), _ptr(h_self), h_self.stride(0) if h_self is not None else 0,
         None, _ptr(csr.inv_deg), _ptr(bias), _ptr(out), out.stride(0), csr.n_rows, D, flags,

@@ -91,6 +91,28 @@ def test_plan_builder_chunks_long_rows():
         assert [s[2] for s in covered[r]] == list(range(first, first + n))
 
 
+def test_plan_builder_i64_rowptr_and_2g_guard():
+    """64-bit row pointers (SURVEY 8b "rowptr i32 or i64"): same plan as the 32-bit builder; a row reaching past 2^31
+    non-zeros is refused with WGNN_ERR_UNSUPPORTED instead of being truncated."""
+    import ctypes as C
+    from scdeepsort_amd import _lib
+    lib = _lib.lib()
+    nnz = np.array([0, 5, 2048, 2049, 10000, 1])
+    rp64 = np.concatenate([[0], np.cumsum(nnz)]).astype(np.int64)
+    ni, nl, npart = C.c_int64(), C.c_int64(), C.c_int64()
+    assert lib.wgnn_plan_build_host_i64(rp64.ctypes.data, None, len(nnz), 2048, None, None, C.addressof(ni), C.addressof(nl),
+                                        C.addressof(npart)) == 0
+    items = np.empty((ni.value, 4), np.int32); longs = np.empty((nl.value, 4), np.int32)
+    assert lib.wgnn_plan_build_host_i64(rp64.ctypes.data, None, len(nnz), 2048, items.ctypes.data, longs.ctypes.data,
+                                        C.addressof(ni), C.addressof(nl), C.addressof(npart)) == 0
+    ref = build_plan(rp64.astype(np.int32), chunk=2048)
+    np.testing.assert_array_equal(items, ref.items.numpy()); np.testing.assert_array_equal(longs, ref.long_rows.numpy())
+    big = np.array([0, 2 ** 31 - 10, 2 ** 31 + 5], dtype=np.int64)
+    assert lib.wgnn_plan_build_host_i64(big.ctypes.data, None, 2, 2048, None, None, C.addressof(ni), C.addressof(nl),
+                                        C.addressof(npart)) == -3
+    assert b"2^31" in lib.wgnn_last_error_string(-3)
+
+
 def test_plan_builder_row_subset():
     nnz = np.array([3, 0, 7, 5000, 2])
     rowptr = np.concatenate([[0], np.cumsum(nnz)]).astype(np.int32)
