@@ -27,7 +27,9 @@ from .graph import CellGeneGraph
 def _device(gpu_id: int) -> torch.device:
     if not torch.cuda.is_available():
         raise WgnnError("the MI355X path needs a GPU (gpu_id=-1 meant CPU in the reference; there is no CPU fallback here)")
-    return torch.device("cuda", max(gpu_id, 0))
+    dev = torch.device("cuda", max(gpu_id, 0))
+    torch.cuda.set_device(dev)                                # the C ABI launches on the current device's streams
+    return dev
 
 
 def _read_expression(path, file_type: str) -> pd.DataFrame:
@@ -139,6 +141,7 @@ class DeepSortClassifier:
         self.learning_rate, self.weight_decay, self.n_epochs, self.n_layers = learning_rate, weight_decay, n_epochs, n_layers
         self.threshold, self.exclude_rate = threshold, exclude_rate
         self.random_seed, self.validation_fraction = random_seed, validation_fraction
+        self.graph_steps = True                               # replay full-size mini-batch steps as one hipGraph each
         self.model: Optional[GNN] = None
         self.history: List[dict] = []
 
@@ -180,7 +183,8 @@ class DeepSortClassifier:
         val_ids = torch.from_numpy(perm[:n_val] + G).to(dev); train_ids = torch.from_numpy(perm[n_val:] + G).to(dev)
         model = GNN(self.dense_dim, self.hidden_dim, len(id2label), self.n_layers, G, activation=F.relu,
                     dropout=self.dropout).to(dev)
-        opt = torch.optim.Adam(model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay)   # train.py:34-35
+        opt = torch.optim.Adam(model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay,    # train.py:34-35
+                               capturable=True)        # step counter on the device: no host sync, hipGraph-capturable
         best, self.history = -1.0, []
         sample_gen = None
         if self.num_neighbors:                                               # train.py:39-40,71-78
@@ -202,15 +206,26 @@ class DeepSortClassifier:
             truth = y[ids - G].cpu().numpy()
             return float((pred == truth).mean()), int((pred < 0).sum())
 
+        def train_step(batch):                                               # train.py:71-87, no host synchronisation
+            logits = model(graph, feats, seeds=batch, num_neighbors=self.num_neighbors, generator=sample_gen)
+            loss = F.cross_entropy(logits, y[batch - G], reduction='sum')    # train.py:36
+            opt.zero_grad(set_to_none=True); loss.backward(); opt.step()
+            return loss.detach()
+
+        step = train_step
+        if self.graph_steps and not self.num_neighbors and len(train_ids) >= 8 * self.batch_size:
+            # full-neighbourhood mini-batches have static shapes: one hipGraph launch per batch (graphed.py).  The
+            # neighbour-subsampled mode draws variable-size NodeFlows and stays eager.
+            from .graphed import GraphedTrainStep
+            step = GraphedTrainStep(train_step, self.batch_size, dev)
+        self._step = step
         for epoch in range(self.n_epochs):
             model.train()
-            total = 0.0
+            total = torch.zeros((), device=dev)
             order = train_ids[torch.randperm(len(train_ids), device=dev)]
-            for batch in torch.split(order, self.batch_size):                # train.py:71-87
-                logits = model(graph, feats, seeds=batch, num_neighbors=self.num_neighbors, generator=sample_gen)
-                loss = F.cross_entropy(logits, y[batch - G], reduction='sum')     # train.py:36
-                opt.zero_grad(); loss.backward(); opt.step()
-                total += float(loss.detach())
+            for batch in torch.split(order, self.batch_size):
+                total += step(batch)                                         # accumulated on the device
+            total = float(total)                                             # ONE read-back per epoch
             tr_acc, _ = accuracy(train_ids)
             va_acc, va_unsure = accuracy(val_ids)
             self.history.append(dict(epoch=epoch, loss=total / max(1, len(train_ids)), train_acc=tr_acc, val_acc=va_acc))

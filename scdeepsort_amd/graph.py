@@ -156,12 +156,66 @@ class AggCsr:
             self._tile_plan[block_rows] = build_tile_plan(self, None, None, block_rows=block_rows)
         return self._tile_plan[block_rows]
 
+    @property
+    def max_row_nnz(self) -> int:
+        """Longest row (host int; one device->host read, cached): sizes the static-shape buffers of seed blocks."""
+        if getattr(self, "_max_row_nnz", None) is None:
+            self._max_row_nnz = int(np.diff(self.rowptr_host).max()) if self.n_rows else 0
+        return self._max_row_nnz
+
     def subplan(self, row_ids: torch.Tensor) -> Tuple[torch.Tensor, Plan]:
-        """Plan restricted to a seed subset (one NodeFlow batch, train.py:71-81).  Not cached: the id
-        tensor's storage may be recycled with other contents between calls."""
-        ids32 = row_ids.to(torch.int32).contiguous()
-        plan = build_plan(self.rowptr_host, None, ids32.cpu().numpy(), device=self.device)
-        return ids32.to(self.device), plan
+        """Plan restricted to a seed subset (one NodeFlow batch, train.py:71-81), built ON THE DEVICE with static
+        shapes: no device->host copy, no host loop, no upload - a mini-batch step never synchronises and can be captured
+        in a hipGraph.  Every seed row is cut into the same number S of equal chunks (S from the batch size and the
+        graph's mean row length, both host-known); S > 1 rows fold their S partial sums in ``agg_finalize`` (fixed
+        order).  Not cached: the id tensor's contents change from batch to batch (a captured step re-runs this)."""
+        dev = self.device
+        ids32 = row_ids.to(device=dev, dtype=torch.int32).contiguous()
+        B = ids32.shape[0]
+        mean_nnz = self.nnz // max(1, self.n_rows)
+        S = max(1, min(8, -(-2048 // max(1, B)), mean_nnz // 128))       # ~2k waves when the batch is small, chunks >= 128 nnz
+        idl = ids32.long()
+        beg = self.rowptr[idl]
+        ln = self.rowptr[idl + 1] - beg
+        cl = (ln + (S - 1)) // S                                         # chunk length of every row
+        s = torch.arange(S, device=dev, dtype=torch.int32).unsqueeze(0)  # [1, S]
+        lo = beg.unsqueeze(1) + torch.minimum(s * cl.unsqueeze(1), ln.unsqueeze(1))
+        hi = beg.unsqueeze(1) + torch.minimum((s + 1) * cl.unsqueeze(1), ln.unsqueeze(1))
+        slot = torch.arange(B, device=dev, dtype=torch.int32).unsqueeze(1).expand(B, S)
+        if S > 1:
+            pslot = slot * S + s
+            long_rows = torch.stack([slot[:, 0], slot[:, 0] * S, torch.full_like(slot[:, 0], S), torch.zeros_like(slot[:, 0])], 1)
+        else:
+            pslot = torch.full_like(slot, -1)
+            long_rows = torch.empty((0, 4), dtype=torch.int32, device=dev)
+        items = torch.stack([slot, lo.to(torch.int32), hi.to(torch.int32), pslot], 2).reshape(B * S, 4).contiguous()
+        return ids32, Plan(items, long_rows.contiguous(), B * S if S > 1 else 0, 0)
+
+    def seed_block_transposed(self, ids32: torch.Tensor):
+        """Source-major view of the in-edges of the seed rows ``ids32`` (one NodeFlow block, train.py:71-81), for the
+        backward of a mini-batch: (t_rowptr int32 [n_cols+1], t_slot int32 [cap], t_val f32 [cap], items int32 [n_cols,4]).
+        Row s lists the seed SLOTS that gather source s, ascending (deterministic summation order, no atomics).
+        Static shapes (cap = batch x longest row, padding sorted behind a sentinel key): no host synchronisation."""
+        dev = self.device
+        B = ids32.shape[0]
+        cap = max(1, B * max(1, self.max_row_nnz))
+        idl = ids32.long()
+        beg = self.rowptr[idl].long()
+        ln = self.rowptr[idl + 1].long() - beg
+        off = torch.cumsum(ln, 0)                                         # inclusive
+        j = torch.arange(cap, device=dev)
+        owner = torch.searchsorted(off, j, right=True).clamp_(max=max(B - 1, 0))
+        valid = j < off[-1] if B else torch.zeros_like(j, dtype=torch.bool)
+        pos = j - (off[owner] - ln[owner])
+        eidx = torch.where(valid, beg[owner] + pos, torch.zeros_like(j))
+        key = torch.where(valid, self.col[eidx].long(), torch.full_like(j, self.n_cols))
+        skey, perm = torch.sort(key, stable=True)                         # ties keep ascending slot order
+        t_slot = owner[perm].to(torch.int32)
+        t_val = torch.where(valid[perm], self.val[eidx[perm]], torch.zeros((), device=dev))
+        t_rowptr = torch.searchsorted(skey, torch.arange(self.n_cols + 1, device=dev)).to(torch.int32)
+        rows = torch.arange(self.n_cols, device=dev, dtype=torch.int32)
+        items = torch.stack([rows, t_rowptr[:-1], t_rowptr[1:], torch.full_like(rows, -1)], 1).contiguous()
+        return t_rowptr, t_slot.contiguous(), t_val.contiguous(), items
 
 
 def _normalize_on_device(rowptr: torch.Tensor, raw: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:

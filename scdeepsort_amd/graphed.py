@@ -4,6 +4,12 @@ Small inputs (the reference's demo tissues, BASELINE cfg1 / cfg2) are launch-bou
 launches of a few microseconds each.  ``GraphedForward`` captures them once into a HIP graph (``torch.cuda.CUDAGraph``;
 the C ABI only enqueues on the stream it is given, never synchronises or allocates, so it is capturable) and replays
 it per call; features are copied into static buffers, logits come back in a static buffer.
+
+``GraphedTrainStep`` does the same for one mini-batch TRAINING step (train.py:71-87: forward on a seed batch, CE-sum
+loss, backward, Adam): the seed sub-plan and the batch's source-major block are built on the device with static shapes
+(``AggCsr.subplan`` / ``seed_block_transposed``), so the whole step is free of host synchronisation and replays as ONE
+graph launch per batch - the reference pays a sampler call, a feature copy and a device->host sync per layer per batch
+(gnn.py:50).
 """
 from __future__ import annotations
 
@@ -40,3 +46,41 @@ class GraphedForward:
             self.features.copy_(features)
         self._g.replay()
         return self.logits
+
+
+class GraphedTrainStep:
+    """``step_fn(batch_ids) -> loss`` (a 0-d device tensor) must do forward + backward + optimizer step with a
+    capturable optimizer (``torch.optim.Adam(..., capturable=True)``) and no host synchronisation.  The first ``warmup``
+    calls run eagerly (they are real training steps); the next full-size batch is captured and every later batch of the
+    same size replays the graph.  Batches of another size (the tail of an epoch) run eagerly."""
+
+    def __init__(self, step_fn, batch_size: int, device: torch.device, warmup: int = 3):
+        self.step_fn, self.batch_size, self.device, self.warmup = step_fn, int(batch_size), device, warmup
+        self._calls, self._g, self._ids, self._loss = 0, None, None, None
+        self._side = torch.cuda.Stream(device=device)
+        self.replays = 0
+
+    def _eager(self, batch):
+        cur = torch.cuda.current_stream(self.device)
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side):
+            loss = self.step_fn(batch)
+        cur.wait_stream(self._side)
+        return loss
+
+    def __call__(self, batch: torch.Tensor) -> torch.Tensor:
+        if batch.shape[0] != self.batch_size:
+            return self._eager(batch)
+        self._calls += 1
+        if self._calls <= self.warmup:
+            return self._eager(batch)
+        if self._g is None:
+            self._ids = batch.clone()
+            self._g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g):
+                self._loss = self.step_fn(self._ids)
+        else:
+            self._ids.copy_(batch)
+        self._g.replay()
+        self.replays += 1
+        return self._loss

@@ -162,6 +162,34 @@ def agg_bwd_src(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, g: torch.
     return dh_src
 
 
+def agg_bwd_src_block(csr: AggCsr, row_ids: torch.Tensor, alpha: Optional[torch.Tensor], mode: int, g: torch.Tensor,
+                      inv_rows: torch.Tensor, h_src: Optional[torch.Tensor], dalpha: Optional[torch.Tensor]) -> torch.Tensor:
+    """K2 for ONE seed batch: ``g`` holds one gradient row per seed SLOT ([B, D]); the source-major structure of the
+    batch's in-edges comes from ``AggCsr.seed_block_transposed`` (device-built, static shapes).  Writes every source
+    row of ``dh_src`` ([n_cols, D]; zero where the batch gathers nothing) and, for SRC_IS_GENE, dalpha[0:n_cols]."""
+    dev = _require_cuda(g, h_src, alpha)
+    ids32 = row_ids.to(device=dev, dtype=torch.int32).contiguous()
+    g = _rowmajor(g.float())
+    D = g.shape[1]
+    if g.shape[0] != ids32.shape[0]:
+        raise WgnnError("g must have one row per seed")
+    dh_src = torch.empty((csr.n_cols, D), dtype=torch.float32, device=dev)
+    if ids32.shape[0] == 0:
+        return dh_src.zero_()
+    t_rowptr, t_slot, t_val, items = csr.seed_block_transposed(ids32)
+    if h_src is not None:
+        h_src = _rowmajor(h_src.float())
+    if alpha is not None:
+        alpha = alpha.reshape(-1).float().contiguous()
+    rc = _lib.call(dev, "wgnn_agg_bwd_src",
+        _ptr(t_rowptr), _ptr(t_slot), _ptr(t_val), _ptr(alpha), mode, _ptr(inv_rows.float().contiguous()),
+        _ptr(g), g.stride(0), _ptr(h_src), h_src.stride(0) if h_src is not None else 0,
+        _ptr(dh_src), dh_src.stride(0), _ptr(dalpha), 0, csr.n_cols, D,
+        _ptr(items), items.shape[0], None, 0, None, 0, _stream(dev))
+    _lib.check(rc, "wgnn_agg_bwd_src")
+    return dh_src
+
+
 def agg_bwd_alpha(csr: AggCsr, g: torch.Tensor, h_src: torch.Tensor, h_self: Optional[torch.Tensor],
                   row_ids: Optional[torch.Tensor] = None, self_compact: bool = False):
     """K3 ``wgnn_agg_bwd_alpha``: per-row alpha gradients for DST_IS_GENE rows and the self-loop scalar."""
@@ -282,18 +310,22 @@ class WeightedMeanAggregate(torch.autograd.Function):
         a = alpha.reshape(-1)
         rows = row_ids.long() if row_ids is not None else None
         inv_rows = csr.inv_deg if rows is None else csr.inv_deg[rows]
-        # destination-row gradient over ALL csr rows (K2 walks the transposed structure)
-        if rows is None:
-            g_full = g
-        else:
-            g_full = torch.zeros((csr.n_rows, D), dtype=torch.float32, device=dev)
-            g_full[rows] = g
         dalpha = torch.zeros_like(a) if ctx.needs_input_grad[2] else None
         need_src = ctx.needs_input_grad[0]
+        want_src_dalpha = dalpha is not None and mode == SRC_IS_GENE
         dh_src = None
-        if need_src or (dalpha is not None and mode == SRC_IS_GENE):
-            dh_src = agg_bwd_src(csr, a if mode != NO_ALPHA else None, mode, g_full,
-                                 h_src if (dalpha is not None and mode == SRC_IS_GENE) else None, dalpha)
+        if need_src or want_src_dalpha:
+            if rows is None:
+                dh_src = agg_bwd_src(csr, a if mode != NO_ALPHA else None, mode, g, h_src if want_src_dalpha else None, dalpha)
+            elif mode != DST_IS_GENE:
+                # seed mini-batch (train.py:71-87): K2 over the source-major view of just the batch's in-edges, built on
+                # the device with static shapes - no [n_rows, D] zero-padded gradient, no pass over the whole graph, no
+                # host synchronisation.  Repeated seeds are separate slots, so their gradients add up.
+                dh_src = agg_bwd_src_block(csr, row_ids, a if mode != NO_ALPHA else None, mode, g, inv_rows,
+                                           h_src if want_src_dalpha else None, dalpha)
+            else:                                       # gene rows as a subset: not produced by GNN; generic route
+                g_full = torch.zeros((csr.n_rows, D), dtype=torch.float32, device=dev).index_add_(0, rows, g)
+                dh_src = agg_bwd_src(csr, a, mode, g_full, None, dalpha)
             dh_src = dh_src.to(h_src.dtype)
         dh_self = None
         hs_rows = None
@@ -305,8 +337,7 @@ class WeightedMeanAggregate(torch.autograd.Function):
                 if rows is None or ctx.self_compact:
                     dh_self = d
                 else:
-                    dh_self = torch.zeros_like(h_self)
-                    dh_self[rows] = d
+                    dh_self = torch.zeros_like(h_self).index_add_(0, rows, d)      # a repeated seed contributes twice
         if dalpha is not None and mode != NO_ALPHA:
             if mode == DST_IS_GENE:
                 d_row, d_self = agg_bwd_alpha(csr, g, h_src, hs_rows, row_ids, self_compact=True if rows is not None else False)

@@ -95,6 +95,30 @@ def test_fit_predict_roundtrip(tmp_path):
 
 
 @pytest.mark.gpu
+def test_fit_replays_minibatch_steps_as_hipgraphs(tmp_path):
+    """Default reference shape (n_layers = 1, train.py:145): full-size mini-batch steps are captured once and replayed
+    (graphed.GraphedTrainStep) - same training outcome as the eager loop."""
+    rng = np.random.default_rng(5)
+    genes = [f"G{i}" for i in range(150)]
+    programs = [np.zeros(150) for _ in range(3)]
+    for t in range(3):
+        programs[t][t * 50:(t + 1) * 50] = 1.0
+    d1, c1, _ = _write_dataset(tmp_path, "mouse_Demo1", 700, rng, genes, programs)
+    hist = {}
+    for graphed in (True, False):
+        clf = sda.DeepSortClassifier("mouse", "Demo", dense_dim=16, hidden_dim=12, batch_size=64, n_epochs=12, n_layers=1,
+                                     learning_rate=0.01, random_seed=4, gpu_id=0, dropout=0.0)
+        clf.graph_steps = graphed
+        clf.fit([(d1, c1)])
+        hist[graphed] = clf.history
+        if graphed:
+            assert clf._step.replays >= 12 * 6                   # 9 full batches per epoch, 3 eager warm-up steps in all
+    assert max(h["val_acc"] for h in hist[True]) > 0.9
+    for a, b in zip(hist[True], hist[False]):                    # dropout 0, same seed -> same trajectory
+        assert a["loss"] == pytest.approx(b["loss"], rel=1e-3)
+
+
+@pytest.mark.gpu
 def test_fit_with_neighbour_subsampling(tmp_path):
     """num_neighbors > 0 (docs/api.rst:62, train.py:37-40): training draws <= k in-edges per node per batch,
     evaluation still uses the full neighbourhood (train.py:92-108)."""
