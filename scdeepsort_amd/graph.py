@@ -166,18 +166,24 @@ class AggCsr:
     def subplan(self, row_ids: torch.Tensor) -> Tuple[torch.Tensor, Plan]:
         """Plan restricted to a seed subset (one NodeFlow batch, train.py:71-81), built ON THE DEVICE with static
         shapes: no device->host copy, no host loop, no upload - a mini-batch step never synchronises and can be captured
-        in a hipGraph.  Every seed row is cut into the same number S of equal chunks (S from the batch size and the
-        graph's mean row length, both host-known); S > 1 rows fold their S partial sums in ``agg_finalize`` (fixed
-        order).  Not cached: the id tensor's contents change from batch to batch (a captured step re-runs this)."""
+        in a hipGraph.  Every seed row gets the same number S = ceil(longest row / chunk) of items, cut at the SAME chunk
+        boundaries as the full-graph plan (later items of short rows are empty); S > 1 rows fold their partial sums in
+        ``agg_finalize`` in chunk order, so a seed's result is bit-identical to its row of the full-graph pass whatever
+        batch it arrives in.  Not cached: the id tensor's contents change from batch to batch (a captured step re-runs
+        this)."""
         dev = self.device
         ids32 = row_ids.to(device=dev, dtype=torch.int32).contiguous()
         B = ids32.shape[0]
-        mean_nnz = self.nnz // max(1, self.n_rows)
-        S = max(1, min(8, -(-2048 // max(1, B)), mean_nnz // 128))       # ~2k waves when the batch is small, chunks >= 128 nnz
+        chunk = max(1, self.plan.chunk)
+        S = max(1, -(-self.max_row_nnz // chunk))
         idl = ids32.long()
         beg = self.rowptr[idl]
         ln = self.rowptr[idl + 1] - beg
-        cl = (ln + (S - 1)) // S                                         # chunk length of every row
+        if S > 64:                                                       # pathological row lengths: S equal chunks per row
+            S = 64
+            cl = (ln + (S - 1)) // S
+        else:
+            cl = torch.full_like(ln, chunk)
         s = torch.arange(S, device=dev, dtype=torch.int32).unsqueeze(0)  # [1, S]
         lo = beg.unsqueeze(1) + torch.minimum(s * cl.unsqueeze(1), ln.unsqueeze(1))
         hi = beg.unsqueeze(1) + torch.minimum((s + 1) * cl.unsqueeze(1), ln.unsqueeze(1))
@@ -365,6 +371,9 @@ def _snake(p: torch.Tensor, n: int) -> torch.Tensor:
     return torch.where(r % 2 == 0, q, n - 1 - q)
 
 
+ONE_ROUND_MIN_NNZ = 20_000_000      # measured: 11.9 M edges even (0.24 vs 0.22 ms), 39.8 M -20 %, 79.8 M -14 %, 159.8 M -13 % (scratch/geom_rounds.py)
+
+
 def auto_tile_geometry(n_rows: int, n_cols: int, n_cus: int = 256, nnz: Optional[int] = None) -> Tuple[int, int]:
     """(n_row_tiles, n_col_splits), from sweeps at 10k..100k cells (``scratch/geom_mid.py``, ``geom_sweep.py``):
     * many rows (>= 40k): whole rounds of ~195..256-row tiles over the CUs, no column split;
@@ -374,9 +383,48 @@ def auto_tile_geometry(n_rows: int, n_cols: int, n_cus: int = 256, nnz: Optional
     if n_rows >= 40_000:
         return -(-min_tiles // n_cus) * n_cus, 1
     n_row_tiles = max(1, -(-n_rows // 250))
+    if nnz is not None and nnz >= ONE_ROUND_MIN_NNZ and n_row_tiles <= n_cus:
+        # big operands: ONE round of <= n_cus workgroups.  Every extra column split costs one more partial-sum row per
+        # destination row (written, then re-read by agg_finalize); at cfg3 the genes<-cells pass went from 80 x 16
+        # tiles / 335 MB of partial sums / 1.42 ms to 85 x 3 / 63 MB / 1.22 ms (scratch/gene_pass_ab.py, round 2).
+        splits = max(1, min(n_cus // n_row_tiles, n_cols // 512 or 1))
+        return max(n_row_tiles, n_cus // splits), splits               # fill the round: e.g. 82 -> 85 x 3 = 255 tiles
     target = 5 * n_cus if nnz is None else min(5 * n_cus, max(160, nnz // 50_000))
     splits = max(1, min(round(target / n_row_tiles), 5 * n_cus // n_row_tiles, n_cols // 512 or 1))
     return n_row_tiles, splits
+
+
+TILE_ORDER = "xcd"       # "xcd" | "split_major" (round-1 order; kept for A/B timing)
+
+
+def _flat_tile_index(n_col_splits: int, n_row_tiles: int, dev) -> torch.Tensor:
+    """[K, R] -> launch position (blockIdx.x) of tile (column split k, row tile t).  Workgroup b runs on XCD b % 8 and
+    every XCD has its own 4 MiB L2, so tiles that stream the SAME source range should share an XCD and run at the same
+    time: with K >= 8 splits (K % 8 == 0) XCD x serves the splits k = x (mod 8); with K = 1, 2, 4 the split k is served
+    by the XCDs x = k (mod K); other K: row-tile-major (neighbouring blocks share a row tile, not a source range).
+    The round-1 order (split-major: b = k*R + t) spread every split over all 8 XCDs, so each L2 fetched the whole
+    source table: 8 x 102 MB per genes<-cells pass at cfg3 instead of 1 x."""
+    K, R = n_col_splits, n_row_tiles
+    k = torch.arange(K, device=dev).unsqueeze(1).expand(K, R)
+    t = torch.arange(R, device=dev).unsqueeze(0).expand(K, R)
+    if TILE_ORDER == "split_major":
+        return k * R + t
+    if K % 8 == 0:
+        x = k % 8                                   # XCD of this split
+        idx = t * (K // 8) + k // 8                 # position in that XCD's list, ordered (row tile, split)
+        return idx * 8 + x
+    if K in (1, 2, 4):
+        per = 8 // K                                # XCDs per split
+        # XCD x = k + K*j (j = 0..per-1) serves split k; deal the row tiles of a split round-robin over its XCDs
+        j = t % per
+        x = k + K * j
+        idx = t // per
+        flat = idx * 8 + x
+        # rows tiles not a multiple of `per`: positions stay unique but may leave holes -> compact by rank
+        order = torch.argsort(flat.reshape(-1))
+        rank = torch.empty_like(order); rank[order] = torch.arange(order.numel(), device=dev)
+        return rank.reshape(K, R)
+    return t * K + k
 
 
 def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits: Optional[int] = 1,
@@ -429,7 +477,9 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
     bounds = torch.arange(n_col_splits + 1, device=dev, dtype=torch.int64) * per_split
     bounds[-1] = S
     bounds = bounds.clamp(max=S)
-    items = torch.full((n_col_splits, n_row_tiles, TILE_ROWS, 4), -1, dtype=torch.int32, device=dev)
+    flat_of = _flat_tile_index(n_col_splits, n_row_tiles, dev)            # [K, R] -> blockIdx.x
+    n_flat = n_col_splits * n_row_tiles
+    items = torch.full((n_flat, TILE_ROWS, 4), -1, dtype=torch.int32, device=dev)
     items[..., 1:3] = 0
     # partial-sum slots: a row needs them when it is split along the columns or into virtual rows
     n_parts_r = k_r * n_col_splits
@@ -439,12 +489,13 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
     n_part = int(pbase[-1])
     o_row, o_part = vrow[order], vpart[order]
     for k in range(n_col_splits):
-        items[k, tile, local, 0] = o_row.to(torch.int32)
+        f = flat_of[k][tile]
+        items[f, local, 0] = o_row.to(torch.int32)
         pslot = pbase[o_row] + o_part * n_col_splits + k
-        items[k, tile, local, 3] = torch.where(needs[o_row], pslot, torch.full_like(pslot, -1)).to(torch.int32)
-    hdr = torch.empty((n_col_splits, n_row_tiles, 2), dtype=torch.int32, device=dev)
-    hdr[..., 0] = bounds[:-1].to(torch.int32).unsqueeze(1)
-    hdr[..., 1] = bounds[1:].to(torch.int32).unsqueeze(1)
+        items[f, local, 3] = torch.where(needs[o_row], pslot, torch.full_like(pslot, -1)).to(torch.int32)
+    hdr = torch.empty((n_flat, 2), dtype=torch.int32, device=dev)
+    hdr[flat_of.reshape(-1), 0] = bounds[:-1].to(torch.int32).unsqueeze(1).expand(n_col_splits, n_row_tiles).reshape(-1)
+    hdr[flat_of.reshape(-1), 1] = bounds[1:].to(torch.int32).unsqueeze(1).expand(n_col_splits, n_row_tiles).reshape(-1)
     lr = torch.nonzero(needs).squeeze(1)
     long_rows = torch.stack([lr, pbase[lr], n_parts_r[lr], torch.zeros_like(lr)], 1).to(torch.int32).contiguous() \
         if lr.numel() else torch.empty((0, 4), dtype=torch.int32, device=dev)
@@ -460,7 +511,7 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
     colv = csr.col.long()
     ksplit = torch.div(colv, per_split, rounding_mode="floor")
     rel = colv - ksplit * per_split
-    key = ((ksplit * n_row_tiles + tile_v[virt]) * nblk_max + torch.div(rel, blk, rounding_mode="floor")) * TILE_WAVES \
+    key = (flat_of[ksplit, tile_v[virt]] * nblk_max + torch.div(rel, blk, rounding_mode="floor")) * TILE_WAVES \
         + wave_v[virt]
     meta = ((slot_v[virt] << 8) | (rel % blk)).to(torch.int32)
     del ksplit, rel, colv
@@ -474,5 +525,5 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
     torch.cumsum(counts, 0, out=seg_ptr[1:])
     entries = torch.stack([meta[perm], csr.val.view(torch.int32)[perm]], 1).contiguous()
     del perm, meta
-    return TilePlan(items.reshape(-1, TILE_ROWS, 4).contiguous(), hdr.reshape(-1, 2).contiguous(), long_rows, n_part,
+    return TilePlan(items.contiguous(), hdr.contiguous(), long_rows, n_part,
                     n_row_tiles, n_col_splits, entries, seg_ptr.to(torch.int32), nblk_max, block_rows)
