@@ -400,31 +400,22 @@ TILE_ORDER = "xcd"       # "xcd" | "split_major" (round-1 order; kept for A/B ti
 def _flat_tile_index(n_col_splits: int, n_row_tiles: int, dev) -> torch.Tensor:
     """[K, R] -> launch position (blockIdx.x) of tile (column split k, row tile t).  Workgroup b runs on XCD b % 8 and
     every XCD has its own 4 MiB L2, so tiles that stream the SAME source range should share an XCD and run at the same
-    time: with K >= 8 splits (K % 8 == 0) XCD x serves the splits k = x (mod 8); with K = 1, 2, 4 the split k is served
-    by the XCDs x = k (mod K); other K: row-tile-major (neighbouring blocks share a row tile, not a source range).
-    The round-1 order (split-major: b = k*R + t) spread every split over all 8 XCDs, so each L2 fetched the whole
-    source table: 8 x 102 MB per genes<-cells pass at cfg3 instead of 1 x."""
+    time.  The split-major tile list (k*R + t) is cut into 8 contiguous chunks, one per XCD, and XCD x's j-th tile is
+    launched at b = 8*j + x: every XCD works through at most ceil(K/8)+1 source ranges, in order.  The round-1 order
+    (b = k*R + t) spread every split over all 8 XCDs, so each L2 fetched the whole source table: 8 x 102 MB per
+    genes<-cells pass at cfg3 instead of ~1.4 x."""
     K, R = n_col_splits, n_row_tiles
     k = torch.arange(K, device=dev).unsqueeze(1).expand(K, R)
     t = torch.arange(R, device=dev).unsqueeze(0).expand(K, R)
+    p = k * R + t
     if TILE_ORDER == "split_major":
-        return k * R + t
-    if K % 8 == 0:
-        x = k % 8                                   # XCD of this split
-        idx = t * (K // 8) + k // 8                 # position in that XCD's list, ordered (row tile, split)
-        return idx * 8 + x
-    if K in (1, 2, 4):
-        per = 8 // K                                # XCDs per split
-        # XCD x = k + K*j (j = 0..per-1) serves split k; deal the row tiles of a split round-robin over its XCDs
-        j = t % per
-        x = k + K * j
-        idx = t // per
-        flat = idx * 8 + x
-        # rows tiles not a multiple of `per`: positions stay unique but may leave holes -> compact by rank
-        order = torch.argsort(flat.reshape(-1))
-        rank = torch.empty_like(order); rank[order] = torch.arange(order.numel(), device=dev)
-        return rank.reshape(K, R)
-    return t * K + k
+        return p
+    chunk = -(-(K * R) // 8)
+    flat = (p % chunk) * 8 + p // chunk                     # holes when 8 does not divide K*R -> compact by rank
+    order = torch.argsort(flat.reshape(-1))
+    rank = torch.empty_like(order)
+    rank[order] = torch.arange(order.numel(), device=dev)
+    return rank.reshape(K, R)
 
 
 def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits: Optional[int] = 1,

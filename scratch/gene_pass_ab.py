@@ -13,7 +13,7 @@ hg = S.synth_features(G, H, device=dev); hc = S.synth_features(C, H, seed=3, dev
 kb = ops.tiled_block_rows(H)
 ref = None
 only = os.environ.get("WGNN_AB_ONLY")
-variants = [("xcd", rt, sp) for (rt, sp) in ((80, 16), (80, 3), (85, 3), (80, 2), (128, 2), (80, 4), (80, 6), (85, 6), (102, 5), (128, 4), (80, 9), (None, None))]
+variants = [(o, rt, sp) for o in ("split_major", "xcd") for (rt, sp) in ((85, 3), (80, 16), (None, None))]
 if only:
     o, rt, sp = only.split(":"); variants = [(o, int(rt) if rt != "None" else None, int(sp) if sp != "None" else None)]
 for order, rt, sp in variants:
