@@ -211,7 +211,9 @@ template <typename TOut, int EPI, bool DBG>
 __global__ void __launch_bounds__(kTW * 64) __attribute__((amdgpu_num_vgpr(32), amdgpu_num_sgpr(80)))
 agg_tiled_flat4(const KArgs a, const TArgs t) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int row_bytes = 1024;
+    constexpr int row_bytes = 1024;                      // LDS row stride: fixed, so that {LDS row address | 4*slot} packs into one dword
+    const int g_row = a.D * (int)sizeof(float);          // global row stride: D <= 256 floats (lanes >= D/4 carry nothing)
+    const int n4 = a.D >> 2;                             // lanes that move 16 B of a row in the global->LDS DMA
     const int kKB = t.kb, buf_bytes = kKB * row_bytes;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -233,18 +235,22 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
     auto fill_rows = [&](int r0, int rows, int buf) {
         const int np = rows > wave ? (rows - wave + kTW - 1) / kTW : 0;        // <= 5 for blocks of <= 80 rows
         if (np == 0) return;
-        const char* g = reinterpret_cast<const char*>(a.src) + ((size_t)r0 + wave) * row_bytes;
+        const char* g = reinterpret_cast<const char*>(a.src) + ((size_t)r0 + wave) * g_row;
         const int l = (int)(size_t)smem + buf * buf_bytes + wave * row_bytes;
+        // EXEC is narrowed to the D/4 lanes that carry data for the duration of the burst (a D < 256 row is shorter than
+        // its 1 KiB LDS slot; the slot's tail is never read by a lane that is stored)
 #define WGNN_FILL_NEXT(K)                                                                                   \
         "s_cmp_lt_u32 %[np], " #K "\n\ts_cbranch_scc1 .Lw4_fd_%=\n\t"                                        \
-        "s_add_u32 m0, m0, 0x4000\n\ts_add_u32 s94, s94, 0x4000\n\ts_addc_u32 s95, s95, 0\n\t"               \
+        "s_add_u32 m0, m0, 0x4000\n\ts_add_u32 s94, s94, s90\n\ts_addc_u32 s95, s95, 0\n\t"               \
         "global_load_lds_dwordx4 %[vo], s[94:95]\n\t"
-        asm volatile("s_mov_b64 s[94:95], %[g]\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\t"
+        asm volatile("s_mov_b64 s[92:93], exec\n\ts_sub_u32 s91, 64, %[n4]\n\ts_lshl_b32 s90, %[n4], 8\n\t"   // s90 = 16 rows x D*4 B
+                     "s_lshr_b64 exec, s[92:93], s91\n\t"                                                       // lanes 0 .. D/4-1
+                     "s_mov_b64 s[94:95], %[g]\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %[vo], s[94:95]\n\t"
                      WGNN_FILL_NEXT(2) WGNN_FILL_NEXT(3) WGNN_FILL_NEXT(4) WGNN_FILL_NEXT(5)
-                     ".Lw4_fd_%=:"
-                     ::[g] "s"(g), [l] "s"(l), [vo] "v"(lane16), [np] "s"(np)
-                     : "m0", "memory", "scc", "s94", "s95");
+                     ".Lw4_fd_%=:\n\ts_mov_b64 exec, s[92:93]"
+                     ::[g] "s"(g), [l] "s"(l), [vo] "v"(lane16), [np] "s"(np), [n4] "s"(n4)
+                     : "m0", "memory", "scc", "s90", "s91", "s92", "s93", "s94", "s95");
 #undef WGNN_FILL_NEXT
     };
     auto fill = [&](int b) { fill_rows(cb + b * kKB, min(kKB, ce - (cb + b * kKB)), b & 1); };
@@ -351,12 +357,18 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
                      "v_mov_b32 %2, v66\n\tv_mov_b32 %3, v67\n\ts_set_gpr_idx_off"
                      : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w) : "s"(i * 4) : "m0");
         if (pslot >= 0) {
-            st4(a.partials + (size_t)pslot * a.D + lane * 4, v);
+            if (lane * 4 < a.D) st4(a.partials + (size_t)pslot * a.D + lane * 4, v);
         } else {
             float4 one[1] = {v};
             epilogue<64, 1, float, TOut, EPI>(a, one, slot, lane, true);
         }
     }
+}
+
+// LDS bytes of one launch: the flat kernel keeps 1 KiB LDS rows whatever D is (+ the per-wave weight strips)
+inline bool use_flat(int D, unsigned flags) { return D <= 256 && !(flags & (1u << 19)); }   // bit 19: force the generic kernel (A/B)
+inline long tiled_lds_bytes(int D, int block_rows, unsigned flags) {
+    return use_flat(D, flags) ? 2L * block_rows * 1024 + kWStripBytes : 2L * block_rows * D * (long)sizeof(float);
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE property of a kernel: the "already raised to" mark is kept
@@ -377,10 +389,10 @@ inline int raise_lds_limit(LdsMarks& marks, const void* fn, int lds) {
 
 template <typename TOut, int EPI>
 int launch_tiled(const KArgs& a, const TArgs& t, long n_tiles, hipStream_t st) {
-    const int lds = 2 * t.kb * a.D * (int)sizeof(float) + (a.D == 256 ? kWStripBytes : 0);
+    const int lds = (int)tiled_lds_bytes(a.D, t.kb, a.flags);
     if (lds > 160 * 1024) return WGNN_ERR_PLAN;
     static LdsMarks generic_marks{}, flat_marks{}, flat_dbg_marks{};      // per instantiation, per device
-    if (a.D == 256 && !(a.flags & (1u << 19))) {       // bit 19: force the generic (row-visit) kernel, for A/B timing
+    if (use_flat(a.D, a.flags)) {
         if (int rc = raise_lds_limit(flat_marks, reinterpret_cast<const void*>(&agg_tiled_flat4<TOut, EPI, false>), lds)) return rc;
         if (a.flags & 0xFFFF0000u)
             if (int rc = raise_lds_limit(flat_dbg_marks, reinterpret_cast<const void*>(&agg_tiled_flat4<TOut, EPI, true>), lds)) return rc;
@@ -416,8 +428,7 @@ extern "C" int wgnn_agg_fwd_tiled(const int32_t* rowptr, const float* alpha, int
     if (!inv_deg && !rowptr && !(flags & WGNN_FLAG_NO_MEAN)) return WGNN_ERR_BAD_ARG;
     if (D <= 0 || D % 4 || ld_out % 4 || (h_self && ld_self % 4)) return WGNN_ERR_ALIGNMENT;
     if (D > 256) return WGNN_ERR_UNSUPPORTED;                     // one float4 per lane
-    if (block_rows < 16 || block_rows > 255 || 2 * (int64_t)block_rows * D * 4 + (D == 256 ? kWStripBytes : 0) > 160 * 1024)
-        return WGNN_ERR_PLAN;
+    if (block_rows < 16 || block_rows > 255 || tiled_lds_bytes(D, block_rows, flags) > 160 * 1024) return WGNN_ERR_PLAN;
     if (!aligned16(h_src) || !aligned16(out) || (h_self && !aligned16(h_self)) || (bias && !aligned16(bias)))
         return WGNN_ERR_ALIGNMENT;
     if (n_tiles > 0 && (!tile_items || !tile_hdr || !entries || !seg_ptr)) return WGNN_ERR_BAD_ARG;
@@ -452,8 +463,7 @@ static int tiled_common_check(int32_t D, int32_t block_rows, const void* entries
                               const float* partials, int64_t n_partials) {
     if (D <= 0 || D % 4) return WGNN_ERR_ALIGNMENT;
     if (D > 256) return WGNN_ERR_UNSUPPORTED;
-    if (block_rows < 16 || block_rows > 255 || 2 * (int64_t)block_rows * D * 4 + (D == 256 ? kWStripBytes : 0) > 160 * 1024)
-        return WGNN_ERR_PLAN;
+    if (block_rows < 16 || block_rows > 255 || tiled_lds_bytes(D, block_rows, 0) > 160 * 1024) return WGNN_ERR_PLAN;
     if (n_tiles < 0 || (n_tiles > 0 && (!tile_items || !tile_hdr || !entries || !seg_ptr))) return WGNN_ERR_BAD_ARG;
     if (n_long > 0 && (!long_rows || !partials || n_partials <= 0)) return WGNN_ERR_WORKSPACE;
     return WGNN_OK;

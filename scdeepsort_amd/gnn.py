@@ -45,16 +45,16 @@ class NodeUpdate(nn.Module):
 
 
 def pad_width(nnz: int, H: int) -> int:
-    """Hidden width as the kernels carry it.  Large graphs run the LDS-streamed kernel, whose hand-scheduled D = 256
-    specialisation is ~2x faster per edge than the generic one at ANY narrower width (measured at cfg3: 2.6-2.8 ms for
-    D = 64..200 vs 1.3 ms at D = 256).  A narrower hidden width - e.g. the reference default hidden_dim = 200,
-    train.py:137 - is therefore carried as 256 columns with zero weights / bias in the padding (exact: the extra
-    columns stay 0 through ReLU and meet zero weight columns in the next layer).  ``nnz`` decides which kernel runs;
-    a sharded job passes the MAX over ranks so that every rank pads alike (the [G, Hp] partial sums are all-reduced)."""
+    """Hidden width as the kernels carry it: the next multiple of 4 (the kernels move float4s; the extra columns get zero
+    weights / bias, stay 0 through ReLU and meet zero weight columns in the next layer).  Round 1 carried EVERY width
+    below 256 as 256 columns on large graphs because only the D = 256 tile kernel was hand-scheduled; since round 2 that
+    kernel runs any D <= 256 natively (1 KiB LDS slots, D/4 lanes in the DMA), so e.g. the reference default
+    hidden_dim = 200 (train.py:137) moves 200-float rows.  ``ops.PAD_NARROW_TO_256`` restores the old behaviour for
+    A/B timing; ``nnz`` (max over ranks in a sharded job, so that every rank decides alike) only matters then."""
     from . import ops
-    if H < 256 and ops.TILED_MIN_WORK is not None and nnz * H >= ops.TILED_MIN_WORK:
+    if ops.PAD_NARROW_TO_256 and H < 256 and ops.TILED_MIN_WORK is not None and nnz * H >= ops.TILED_MIN_WORK:
         return 256
-    return -(-H // 4) * 4                                  # the kernels move float4s: widths are multiples of 4
+    return -(-H // 4) * 4
 
 
 def _is_relu(fn) -> bool:

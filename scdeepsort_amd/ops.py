@@ -50,6 +50,7 @@ def _dtype_code(t: torch.Tensor) -> int:
 PROFILE = None
 DEBUG_FLAGS = 0      # ablation switches of the tiled kernel (timing experiments only)
 # K1 dispatch: passes with nnz*D above this go to the LDS-streamed kernel (None = always row-wave)
+PAD_NARROW_TO_256 = False           # round-1 behaviour (hidden < 256 carried as 256 zero-padded columns); kept for A/B timing
 TILED_MIN_WORK = 500_000_000        # nnz*D above which the LDS-streamed kernels win (measured crossover: ~2 M edges at D = 256)
 
 
@@ -229,9 +230,10 @@ def agg_bwd_alpha(csr: AggCsr, g: torch.Tensor, h_src: torch.Tensor, h_self: Opt
 
 
 def tiled_block_rows(D: int) -> int:
-    """Source rows per LDS block: at D = 256, 78 x 1 KiB x 2 buffers + the 4 KiB of per-wave weight strips = all
-    160 KiB of a CU (measured best); else 64."""
-    return 78 if D == 256 else 64
+    """Source rows per LDS block of the tile kernels: 78 x 1 KiB x 2 buffers + the 4 KiB of per-wave weight strips = all
+    160 KiB of a CU (measured best).  The flat kernel keeps 1 KiB LDS rows for every D <= 256 (a narrower row fills the
+    head of its slot; only D/4 lanes take part in the global->LDS DMA)."""
+    return 78
 
 
 def agg_fwd_tiled(csr: AggCsr, tplan, alpha: Optional[torch.Tensor], mode: int, self_idx: int,
@@ -271,7 +273,7 @@ def agg_fwd_tiled(csr: AggCsr, tplan, alpha: Optional[torch.Tensor], mode: int, 
     if ev is not None:
         ev[1].record(torch.cuda.current_stream(dev))
         PROFILE.append((("rows", csr.n_rows, "cols", csr.n_cols, "nnz", csr.nnz, "D", D, "mode", mode,
-                         "kernel", "agg_tiled_flat4" if D == 256 else "agg_tiled"), ev[0], ev[1]))
+                         "kernel", "agg_tiled_flat4"), ev[0], ev[1]))
     return out
 
 

@@ -112,7 +112,8 @@ def test_world2_hip_sharded_engine_matches_unsharded_oracle(tmp_path, hidden, dr
 
 def _pad_worker(rank, world, port, out_dir):
     """the zero-padding decision of a narrow hidden width must be rank-invariant.  Rank 0's shard is above the
-    tile-kernel threshold, rank 1's below: both must carry 256 columns or the [G, Hp] all-reduce mismatches."""
+    tile-kernel threshold, rank 1's below: both must carry 256 columns or the [G, Hp] all-reduce mismatches.  (Since
+    round 2 narrow widths run natively and nothing is padded by default; the legacy route is switched on here.)"""
     import torch.nn.functional as F
     import scdeepsort_amd as sda
     from scdeepsort_amd import dist as D, ops, synthetic as S
@@ -128,6 +129,7 @@ def _pad_worker(rank, world, port, out_dir):
         nnz = [torch.zeros(1, dtype=torch.long, device=dev) for _ in range(world)]
         dist.all_gather(nnz, torch.tensor([col.shape[0]], device=dev))
         n0, n1 = int(nnz[0]), int(nnz[1])
+        ops.PAD_NARROW_TO_256 = True                             # the round-1 route, where the width depends on the kernel choice
         ops.TILED_MIN_WORK = (n0 + n1) // 2 * H                  # rank 0 above, rank 1 below
         assert n0 * H >= ops.TILED_MIN_WORK > n1 * H
         torch.manual_seed(0)

@@ -282,11 +282,13 @@ def test_full_size_properties_cfg3():
 
 
 # ---- LDS-streamed (tiled) kernel: same outputs as the oracle, every geometry -------------------
-@pytest.mark.parametrize("D", [64, 128, 256])
+@pytest.mark.parametrize("D", [4, 64, 128, 200, 252, 256])
 @pytest.mark.parametrize("geom", [(None, 1), (3, 1), (2, 4), (5, 7)])
 @pytest.mark.parametrize("direction", ["cells", "genes"])
 @pytest.mark.parametrize("kb", [64, 78])
 def test_tiled_kernel_matches_oracle(D, geom, direction, kb):
+    """The hand-scheduled tile kernel (agg_tiled_flat4) at every width it serves natively: D = 256 and narrower rows
+    (reference default hidden_dim = 200, train.py:137; D/4 lanes in the DMA, 1 KiB LDS slots), all tile geometries."""
     from scdeepsort_amd.graph import build_tile_plan
     from scdeepsort_amd import ops
     c = small_case(cells=700, genes=333, dim=D, seed=D + 7, density=0.25, test_cells=50)
@@ -335,6 +337,27 @@ def test_flat_kernel_many_blocks(kb, direction):
     ops.PROFILE = None
     assert kernels == {"agg_tiled_flat4"}
     np.testing.assert_allclose(out.cpu().numpy(), want, atol=TOL)
+
+
+@pytest.mark.parametrize("D", [64, 200, 256])
+def test_generic_tile_kernel_still_matches(D):
+    """agg_tiled (compiler-scheduled, kept for A/B timing behind debug flag bit 19) against the flat kernel: same bits
+    are not required (different summation order), same result to 1e-4 is."""
+    from scdeepsort_amd.graph import build_tile_plan
+    from scdeepsort_amd import ops
+    c = small_case(cells=500, genes=260, dim=D, seed=D, density=0.2, test_cells=0)
+    g = sda.CellGeneGraph.from_expression(c["expr"], device=DEV)
+    G = c["G"]
+    alpha = dev(np.random.default_rng(1).uniform(0.5, 1.5, G + 2).astype(np.float32))
+    Hg, Hc = dev(c["feats"][:G]), dev(c["feats"][G:])
+    tp = build_tile_plan(g.cg, 3, 2, block_rows=64)
+    flat = ops.agg_fwd_tiled(g.cg, tp, alpha, sda.SRC_IS_GENE, G + 1, Hg, Hc)
+    ops.DEBUG_FLAGS = 1 << 19
+    try:
+        gen = ops.agg_fwd_tiled(g.cg, tp, alpha, sda.SRC_IS_GENE, G + 1, Hg, Hc)
+    finally:
+        ops.DEBUG_FLAGS = 0
+    np.testing.assert_allclose(gen.cpu().numpy(), flat.cpu().numpy(), atol=2e-5)
 
 
 def test_tiled_plan_covers_every_edge_once():
@@ -581,10 +604,11 @@ def test_fp16_stored_features_match_oracle_on_rounded_inputs():
         np.testing.assert_allclose(got, want, atol=TOL, err_msg=order)
 
 
-@pytest.mark.parametrize("hidden", [200, 64])
-def test_narrow_hidden_is_carried_as_256_columns_on_the_tiled_path(hidden):
-    """Reference default hidden_dim = 200 (train.py:137): on graphs big enough for the LDS-streamed kernel the hidden
-    width is zero-padded to 256 so the D = 256 specialisation runs; logits and gradients are unchanged."""
+@pytest.mark.parametrize("hidden,legacy_pad", [(200, False), (64, False), (50, False), (200, True)])
+def test_narrow_hidden_on_the_tiled_path(hidden, legacy_pad):
+    """Reference default hidden_dim = 200 (train.py:137) on graphs big enough for the LDS-streamed kernel: the tile
+    kernel moves the 200-float rows natively (round 1 carried them as 256 zero-padded columns; `legacy_pad` keeps that
+    route covered).  Logits and gradients match the oracle either way; hidden 50 is carried as 52 columns."""
     from scdeepsort_amd import ops
     c = small_case(cells=300, genes=180, dim=260, hidden=hidden, n_classes=6, seed=51, test_cells=0)
     G = c["G"]
@@ -597,8 +621,9 @@ def test_narrow_hidden_is_carried_as_256_columns_on_the_tiled_path(hidden):
     m = make_model(sd, 260, hidden, 6, 2, G)
     saved = ops.TILED_MIN_WORK
     ops.TILED_MIN_WORK = 1
+    ops.PAD_NARROW_TO_256 = legacy_pad
     try:
-        assert m._pad_width(g, hidden) == 256
+        assert m._pad_width(g, hidden) == (256 if legacy_pad else -(-hidden // 4) * 4)
         ops.PROFILE = []
         logits = m(g, dev(c["feats"]))
         kernels = {dict(zip(t[::2], t[1::2]))["kernel"] for t, _, _ in ops.PROFILE}
@@ -609,6 +634,7 @@ def test_narrow_hidden_is_carried_as_256_columns_on_the_tiled_path(hidden):
     finally:
         ops.TILED_MIN_WORK = saved
         ops.PROFILE = None
+        ops.PAD_NARROW_TO_256 = False
     assert logits.shape == (c["C"], 6)
     np.testing.assert_allclose(logits.detach().cpu().numpy(), logits_ref.detach().numpy(), atol=TOL)
     for n, p in m.named_parameters():
@@ -770,13 +796,16 @@ def test_predict_graph_with_only_test_cells_and_tiny_graphs():
     np.testing.assert_allclose(got1, O.csr_forward(sd1, O.build_csr_graph(one), f1, 2), atol=TOL)
 
 
-def test_sharded_engine_carries_narrow_hidden_padded():
-    """ShardedWgnn on the LDS-streamed path: hidden 32 carried as 256 columns through both layers and the head; two
-    simulated shards (partial gene sums added by hand) reproduce the unsharded logits."""
+@pytest.mark.parametrize("legacy_pad", [False, True])
+def test_sharded_engine_narrow_hidden_on_the_tiled_path(legacy_pad):
+    """ShardedWgnn on the LDS-streamed path with hidden 30: carried as 32 columns natively (or as 256 zero-padded ones
+    on the round-1 route) through both layers and the head; two simulated shards (partial gene sums added by hand)
+    reproduce the unsharded logits."""
     from scdeepsort_amd import ops, synthetic as S
     from scdeepsort_amd.sharded import ShardedWgnn
     from scdeepsort_amd.dist import shard_range
-    G, C, Din, H = 300, 1000, 40, 32
+    G, C, Din, H = 300, 1000, 40, 30
+    Hp = 256 if legacy_pad else 32
     rp, col, val = S.synth_expression(C, G, 0.08, device=DEV)
     torch.manual_seed(1)
     m = sda.GNN(Din, H, 5, 2, G, activation=F.relu).to(DEV).eval()
@@ -787,6 +816,7 @@ def test_sharded_engine_carries_narrow_hidden_padded():
         want = m(sda.CellGeneGraph.from_device_csr(rp, col, val, G), feats)
     saved = ops.TILED_MIN_WORK
     ops.TILED_MIN_WORK = 1
+    ops.PAD_NARROW_TO_256 = legacy_pad
     try:
         with torch.no_grad():
             shards = []
@@ -798,7 +828,7 @@ def test_sharded_engine_carries_narrow_hidden_padded():
             gstats = (stats[0][0] + stats[1][0], stats[0][1] + stats[1][1])
             eng = [ShardedWgnn.build(m, r_, c_, v_, G, global_stats=gstats) for _, _, r_, c_, v_ in shards]
             (W1, b1), (W2, b2), (Wo, bo) = eng[0]._weights()
-            assert W1.shape == (256, Din) and W2.shape == (256, 256) and Wo.shape == (5, 256)
+            assert W1.shape == (Hp, Din) and W2.shape == (Hp, Hp) and Wo.shape == (5, Hp)
             p_g = F.linear(feats[:G], W1)
             p_c = [F.linear(feats[G + lo:G + hi], W1) for lo, hi, *_ in shards]
             new_c = [e._ops().cells_layer(p_g, pc, b1, True) for e, pc in zip(eng, p_c)]
@@ -809,6 +839,7 @@ def test_sharded_engine_carries_narrow_hidden_padded():
             got = torch.cat([F.linear(o, Wo, bo) for o in out])
     finally:
         ops.TILED_MIN_WORK = saved
+        ops.PAD_NARROW_TO_256 = False
     np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), atol=2e-5)
 
 
