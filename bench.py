@@ -137,6 +137,10 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    try:                                             # the dense projections are plain library GEMMs: hipBLASLt's fp32 kernels
+        torch.backends.cuda.preferred_blas_library("hipblaslt")      # ran ~10 % faster than the default choice on these shapes
+    except Exception:                                                # (scratch/gemm_tune.py, round 2)
+        pass
 
     import scdeepsort_amd as sda
     from scdeepsort_amd import ops, synthetic as S

@@ -107,6 +107,28 @@ def build_plan(rowptr_host: np.ndarray, chunk: Optional[int] = None, row_ids_hos
     return Plan(torch.from_numpy(items).to(device), torch.from_numpy(longs).to(device), int(npart.value), chunk)
 
 
+def device_plan(rowptr32: torch.Tensor, n_rows: int, max_row_nnz: int, chunk: int) -> Plan:
+    """Row-chunk plan built ON THE DEVICE with static shapes (no device->host copy): every row gets the same number
+    S = ceil(max_row_nnz / chunk) of items cut at multiples of ``chunk`` (later items of short rows are empty); S > 1
+    rows fold their S partial sums in ``agg_finalize``.  ``max_row_nnz`` is a host-known BOUND on the row length."""
+    dev = rowptr32.device
+    chunk = max(1, int(chunk))
+    S = max(1, -(-int(max_row_nnz) // chunk))
+    beg, ln = rowptr32[:-1], rowptr32[1:] - rowptr32[:-1]
+    s = torch.arange(S, device=dev, dtype=torch.int32).unsqueeze(0)
+    lo = beg.unsqueeze(1) + torch.minimum(s * chunk, ln.unsqueeze(1))
+    hi = beg.unsqueeze(1) + torch.minimum((s + 1) * chunk, ln.unsqueeze(1))
+    slot = torch.arange(n_rows, device=dev, dtype=torch.int32).unsqueeze(1).expand(n_rows, S)
+    if S > 1:
+        pslot = slot * S + s
+        long_rows = torch.stack([slot[:, 0], slot[:, 0] * S, torch.full_like(slot[:, 0], S), torch.zeros_like(slot[:, 0])], 1)
+    else:
+        pslot = torch.full_like(slot, -1)
+        long_rows = torch.empty((0, 4), dtype=torch.int32, device=dev)
+    items = torch.stack([slot, lo, hi, pslot], 2).reshape(n_rows * S, 4).contiguous()
+    return Plan(items, long_rows.contiguous(), n_rows * S if S > 1 else 0, chunk)
+
+
 @dataclass
 class AggCsr:
     """One aggregation direction: destination-major CSR + normalised values + plan."""
@@ -117,7 +139,7 @@ class AggCsr:
     n_rows: int
     n_cols: int
     plan: Plan
-    rowptr_host: np.ndarray
+    rowptr_host: Optional[np.ndarray]    # None for blocks built on the device (sampler): then ``row_nnz_bound`` is set
     _t: Optional["AggCsr"] = field(default=None, repr=False)
     _tile_plan: Optional[object] = field(default=None, repr=False)
 
@@ -142,9 +164,13 @@ class AggCsr:
             t_col = rows[order].contiguous()
             t_val = self.val[order].contiguous()
             t_rowptr32 = t_rowptr.to(torch.int32)
-            host = t_rowptr32.cpu().numpy()
-            self._t = AggCsr(t_rowptr32, t_col, t_val, torch.empty(0, device=dev), self.n_cols, self.n_rows,
-                             build_plan(host, self.plan.chunk, device=dev), host)
+            if self.rowptr_host is None:             # device-built block: a source feeds at most every row once
+                plan, host = device_plan(t_rowptr32, self.n_cols, max(1, self.n_rows), DEFAULT_CHUNK), None
+            else:
+                host = t_rowptr32.cpu().numpy()
+                plan = build_plan(host, self.plan.chunk, device=dev)
+            self._t = AggCsr(t_rowptr32, t_col, t_val, torch.empty(0, device=dev), self.n_cols, self.n_rows, plan, host)
+            self._t._max_row_nnz = self.n_rows if host is None else None
         return self._t
 
     def tile_plan(self, block_rows: int = 64):
@@ -160,6 +186,8 @@ class AggCsr:
     def max_row_nnz(self) -> int:
         """Longest row (host int; one device->host read, cached): sizes the static-shape buffers of seed blocks."""
         if getattr(self, "_max_row_nnz", None) is None:
+            if self.rowptr_host is None:
+                raise _lib.WgnnError("device-built block without a row-length bound")
             self._max_row_nnz = int(np.diff(self.rowptr_host).max()) if self.n_rows else 0
         return self._max_row_nnz
 

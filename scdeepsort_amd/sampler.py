@@ -16,7 +16,7 @@ from typing import List, Optional, Tuple
 
 import torch
 
-from .graph import AggCsr, CellGeneGraph, build_plan
+from .graph import AggCsr, CellGeneGraph, device_plan
 
 
 @dataclass
@@ -54,9 +54,12 @@ def sample_block(csr: AggCsr, rows: torch.Tensor, k: int, gen: Optional[torch.Ge
     eidx = (beg[owner] + pos)[real]                            # edge positions in the parent CSR (row-major, ascending)
     inv = 1.0 / (m_real.float() + self_drawn).clamp(min=1.0)
     rowptr32 = rowptr.to(torch.int32)
-    host = rowptr32.cpu().numpy()
+    bound = max(1, min(int(k), csr.max_row_nnz))               # host-known bound on the drawn row length
+    # plan on the device (every row holds <= k drawn edges): no row-pointer read-back.  What remains host-visible per
+    # block is the number of candidate edges (`total`, sizes the random draw) - a NodeFlow's sizes are data-dependent.
     sub = AggCsr(rowptr32, csr.col[eidx].contiguous(), csr.val[eidx].contiguous(), inv.contiguous(), n, csr.n_cols,
-                 build_plan(host, csr.plan.chunk, device=dev), host)
+                 device_plan(rowptr32, n, bound, max(1, csr.plan.chunk)), None)
+    sub._max_row_nnz = bound
     return SampledBlock(rows, sub, self_drawn)
 
 

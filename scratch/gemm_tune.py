@@ -21,3 +21,22 @@ try:
     t3=[timeit(lambda: F.linear(x,w)) for x,w,b in xs]
     print('tunable      ', [round(t,1) for t in t3], 'sum', round(sum(t3),1), 'tuning took', round(time.time()-t0,1),'s')
 except Exception as e: print('tunable n/a', e)
+# round 2: other formulations of the big projection (M=100k, K=400, N=256)
+try:
+    import torch.cuda.tunable as tn
+    tn.enable(False)
+except Exception:
+    pass
+x, w, b = xs[0]
+wt = w.t().contiguous()
+print('x @ Wt (contig)', round(timeit(lambda: x @ wt), 1))
+xp = F.pad(x, (0, 16)); wp = F.pad(w, (0, 16))
+print('K padded to 416', round(timeit(lambda: F.linear(xp, wp)), 1))
+xp = F.pad(x, (0, 48)); wp = F.pad(w, (0, 48))
+print('K padded to 448', round(timeit(lambda: F.linear(xp, wp)), 1))
+xa = torch.randn(120000, 400, device=dev)
+print('genes+cells in one GEMM (120k x 400 x 256)', round(timeit(lambda: F.linear(xa, w)), 1))
+out = torch.empty(100000, 256, device=dev)
+print('addmm out=', round(timeit(lambda: torch.mm(x, wt, out=out)), 1))
+x16 = x.half(); w16 = w.half()
+print('fp16 inputs (reference only, NOT the product dtype)', round(timeit(lambda: F.linear(x16, w16)), 1))
