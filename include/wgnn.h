@@ -230,6 +230,35 @@ int wgnn_agg_bwd_alpha_tiled(const float* inv_deg, const float* g, int64_t ld_g,
 int wgnn_normalize_rows(const int32_t* rowptr, const float* val_in, float* val_out, float* inv_deg,
                         int64_t n_rows, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Dense half of a layer on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, an fmaf chain in k order):
+ *     out[M, N] = act( x[M, K] . w[N, K]^T + bias[N] )
+ * = NodeUpdate.forward's `activation(fc_neigh(neigh))` (models/gnn.py:18-25; w / bias in nn.Linear's layout) and the
+ * classifier head `linear(h)` (models/gnn.py:66-67).  flags: WGNN_FLAG_RELU or 0.  K, ld_x, ld_w multiples of 4,
+ * x / w 16-byte aligned; M, N arbitrary.  bias may be NULL.  Makes the ABI self-sufficient for one whole layer.
+ * ------------------------------------------------------------------------- */
+int wgnn_linear_fwd(const float* x, int64_t ld_x, const float* w, int64_t ld_w, const float* bias,
+                    float* out, int64_t ld_out, int64_t M, int32_t N, int32_t K, uint32_t flags, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * One reference layer on a block in the reference's literal order (SURVEY 8b's optional fused entry):
+ *     neigh = nf.block_compute(i, message_func, fn.mean('m','neigh'))   (models/gnn.py:47-56,65)  = wgnn_agg_fwd (f32)
+ *     out   = relu(fc_neigh(neigh))                                      (models/gnn.py:18-25)     = wgnn_linear_fwd
+ * Arguments up to n_partials as wgnn_agg_fwd (f32 in/out, no bias, agg_flags without WGNN_FLAG_RELU);
+ * neigh_scratch: float[n_out * D] (caller-owned); W: float[H, ld_w] (nn.Linear layout), bias: float[H] or NULL;
+ * lin_flags: WGNN_FLAG_RELU or 0; out: float[n_out, ld_out].
+ * ------------------------------------------------------------------------- */
+int wgnn_agg_linear_relu_fwd(const int32_t* rowptr, const int32_t* col, const float* val,
+                             const float* alpha, int alpha_mode, int32_t self_idx,
+                             const float* h_src, int64_t ld_src, const float* h_self, int64_t ld_self,
+                             const int32_t* row_ids, const float* inv_deg,
+                             int64_t n_out, int32_t D, uint32_t agg_flags,
+                             const int32_t* items, int64_t n_items, const int32_t* long_rows, int64_t n_long,
+                             float* partials, int64_t n_partials,
+                             float* neigh_scratch,
+                             const float* W, int64_t ld_w, const float* bias, int32_t H, uint32_t lin_flags,
+                             float* out, int64_t ld_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

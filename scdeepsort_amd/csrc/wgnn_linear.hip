@@ -1,0 +1,161 @@
+// wgnn_linear.hip - the dense half of a layer on the fp32 matrix cores (gfx950):
+//
+//     out = act( X . W^T + bias )          NodeUpdate.forward = relu(fc_neigh(neigh))   (reference models/gnn.py:18-25)
+//                                          classifier head    = linear(h)               (reference models/gnn.py:66-67)
+//
+// Why it exists: (1) the C ABI (include/wgnn.h) is otherwise not self-sufficient for one whole layer - a non-torch
+// caller would have to bring its own GEMM; (2) SURVEY 8b lists the fused `wgnn_agg_linear_relu_fwd`; (3) north_star
+// allows MFMA where the dense feature x weight projection matters: at BASELINE cfg3 the projections are 40 GFLOP =
+// ~11 % of a forward.  v_mfma_f32_32x32x2_f32 is EXACT fp32 (bitwise an fmaf chain in k order, MI355X_MICROARCH.md) at
+// the fp32 vector rate (157 TF chip peak), so parity with the oracle's fp32 Linear needs no tolerance beyond summation
+// order.
+//
+// Kernel: 128 x 128 output tile per 256-thread workgroup (4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA blocks of
+// 32 x 32, 64 accumulator VGPRs), K walked in slabs of 16 staged in LDS (row stride 17 floats: the per-lane fragment
+// reads `As[(row)*17 + k]` hit 32 distinct banks), next slab's global loads issued before the current slab's MFMAs,
+// two LDS buffers, one barrier per slab.  M, N, K need only be multiples of 4 (K) / 1 (M, N): edges are guarded.
+#include "wgnn_common.h"
+
+namespace {
+using namespace wgnn;
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#ifndef WGNN_LIN_BK
+#define WGNN_LIN_BK 16
+#endif
+constexpr int kBM = 128, kBN = 128, kBK = WGNN_LIN_BK, kLd = kBK + 1;
+constexpr int kLinThreads = 256;
+
+struct LinArgs {
+    const float* x; long ld_x;
+    const float* w; long ld_w;
+    const float* bias;
+    float* out; long ld_out;
+    long M; int N; int K; unsigned flags;
+};
+
+__global__ void __launch_bounds__(kLinThreads) linear_mfma_f32(const LinArgs a) {
+    __shared__ float As[2][kBM * kLd];
+    __shared__ float Ws[2][kBN * kLd];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    // column tiles vary fastest: the workgroups that share a row tile of X run together
+    const long m0 = (long)(blockIdx.x / ((a.N + kBN - 1) / kBN)) * kBM;
+    const int n0 = (int)(blockIdx.x % ((a.N + kBN - 1) / kBN)) * kBN;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // global -> registers: thread t moves 2 float4 of X and 2 of W per slab (rows t/4 and t/4 + 64, k offset (t%4)*4)
+    constexpr int kTPR = kBK / 4;                              // threads per tile row (one float4 each)
+    constexpr int kRPP = kLinThreads / kTPR;                   // tile rows covered per pass
+    constexpr int kNP = kBM / kRPP;                            // passes
+    const int lr = t / kTPR, lk = (t % kTPR) * 4;
+    float4 xa[kNP], wa[kNP];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < kNP; ++i) {
+            const long row = m0 + lr + kRPP * i;
+            const int col = n0 + lr + kRPP * i;
+            const bool kin = k0 + lk < a.K;                    // K % 4 == 0: a float4 is inside or outside as a whole
+            xa[i] = (row < a.M && kin) ? ld4(a.x + row * a.ld_x + k0 + lk) : make_float4(0.f, 0.f, 0.f, 0.f);
+            wa[i] = (col < a.N && kin) ? ld4(a.w + (long)col * a.ld_w + k0 + lk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < kNP; ++i) {
+            float* pa = &As[buf][(lr + kRPP * i) * kLd + lk];
+            pa[0] = xa[i].x; pa[1] = xa[i].y; pa[2] = xa[i].z; pa[3] = xa[i].w;
+            float* pw = &Ws[buf][(lr + kRPP * i) * kLd + lk];
+            pw[0] = wa[i].x; pw[1] = wa[i].y; pw[2] = wa[i].z; pw[3] = wa[i].w;
+        }
+    };
+
+    const int nslab = (a.K + kBK - 1) / kBK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int fr = lane & 31, fk = lane >> 5;                  // fragment: A[i = l&31][k = l>>5], B[k = l>>5][j = l&31]
+    for (int s = 0; s < nslab; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nslab) gload((s + 1) * kBK);               // in flight during this slab's MFMAs
+        const float* pa = &As[buf][(wm * 64 + fr) * kLd + fk];
+        const float* pw = &Ws[buf][(wn * 64 + fr) * kLd + fk];
+#pragma unroll
+        for (int kk = 0; kk < kBK; kk += 2) {
+            const float a0 = pa[kk], a1 = pa[32 * kLd + kk];
+            const float b0 = pw[kk], b1 = pw[32 * kLd + kk];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (s + 1 < nslab) lstore(buf ^ 1);                    // the other buffer: last read two slabs ago
+        __syncthreads();
+    }
+
+    // C/D map of the 32x32 forms: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const bool relu = a.flags & WGNN_FLAG_RELU;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + fr;
+            if (col >= a.N) continue;
+            const float bv = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (row < a.M) {
+                    float v = acc[i][j][r] + bv;
+                    if (relu) v = fmaxf(v, 0.f);
+                    a.out[row * a.ld_out + col] = v;
+                }
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" int wgnn_linear_fwd(const float* x, int64_t ld_x, const float* w, int64_t ld_w, const float* bias,
+                               float* out, int64_t ld_out, int64_t M, int32_t N, int32_t K, uint32_t flags, void* stream) {
+    if (!x || !w || !out || M < 0 || N <= 0 || K <= 0) return WGNN_ERR_BAD_ARG;
+    if (flags & ~WGNN_FLAG_RELU) return WGNN_ERR_BAD_ARG;
+    if (K % 4 || ld_x % 4 || ld_w % 4 || !aligned16(x) || !aligned16(w)) return WGNN_ERR_ALIGNMENT;
+    if (ld_x < K || ld_w < K || ld_out < N) return WGNN_ERR_BAD_ARG;
+    if (M == 0) return WGNN_OK;
+    const long tiles = ((M + kBM - 1) / kBM) * ((N + kBN - 1) / kBN);
+    if (tiles > 0x7FFFFFFFL) return WGNN_ERR_UNSUPPORTED;
+    LinArgs a{x, (long)ld_x, w, (long)ld_w, bias, out, (long)ld_out, (long)M, N, K, flags};
+    hipLaunchKernelGGL(linear_mfma_f32, dim3((unsigned)tiles), dim3(kLinThreads), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? WGNN_OK : WGNN_ERR_LAUNCH;
+}
+
+// One whole reference layer on a block, in the reference's literal order (aggregate, then NodeUpdate):
+//     neigh = block_compute(message_func, fn.mean)        (gnn.py:47-56,65)    -> K1 into `neigh_scratch`
+//     out   = relu(fc_neigh(neigh))                        (gnn.py:18-25)       -> wgnn_linear_fwd
+extern "C" int wgnn_agg_linear_relu_fwd(const int32_t* rowptr, const int32_t* col, const float* val,
+                                        const float* alpha, int alpha_mode, int32_t self_idx,
+                                        const float* h_src, int64_t ld_src, const float* h_self, int64_t ld_self,
+                                        const int32_t* row_ids, const float* inv_deg,
+                                        int64_t n_out, int32_t D, uint32_t agg_flags,
+                                        const int32_t* items, int64_t n_items, const int32_t* long_rows, int64_t n_long,
+                                        float* partials, int64_t n_partials,
+                                        float* neigh_scratch,
+                                        const float* W, int64_t ld_w, const float* bias, int32_t H, uint32_t lin_flags,
+                                        float* out, int64_t ld_out, void* stream) {
+    if (!neigh_scratch || !aligned16(neigh_scratch)) return WGNN_ERR_WORKSPACE;
+    if (agg_flags & WGNN_FLAG_RELU) return WGNN_ERR_BAD_ARG;           // the activation belongs to the dense half here
+    int rc = wgnn_agg_fwd(rowptr, col, val, alpha, alpha_mode, self_idx, h_src, ld_src, h_self, ld_self, row_ids, inv_deg,
+                          nullptr, neigh_scratch, D, n_out, D, WGNN_F32, WGNN_F32, agg_flags, items, n_items, long_rows,
+                          n_long, partials, n_partials, stream);
+    if (rc) return rc;
+    return wgnn_linear_fwd(neigh_scratch, D, W, ld_w, bias, out, ld_out, n_out, H, D, lin_flags, stream);
+}

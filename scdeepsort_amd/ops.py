@@ -383,3 +383,29 @@ class _WeightedSum(torch.autograd.Function):
 
 def weighted_sum(csr: AggCsr, h_src: torch.Tensor) -> torch.Tensor:
     return _WeightedSum.apply(h_src, csr)
+
+
+# ------------------------------------------------------------------------------------------------
+# dense half of a layer through the C ABI (fp32 matrix cores) - see csrc/wgnn_linear.hip
+# ------------------------------------------------------------------------------------------------
+USE_WGNN_LINEAR = False      # GNN's projections: False = torch.nn.functional.linear (library GEMM), True = wgnn_linear_fwd
+
+
+def linear_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
+    """``act(x @ weight.T + bias)`` with ``wgnn_linear_fwd`` (v_mfma_f32_32x32x2_f32, exact fp32).  Inference helper: no
+    autograd (training keeps torch's Linear, whose backward is a library GEMM as well)."""
+    dev = _require_cuda(x, weight, bias)
+    x = _rowmajor(x.float()); weight = _rowmajor(weight.float())
+    M, K = x.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K:
+        raise WgnnError("x and weight disagree on K")
+    if K % 4:
+        raise WgnnError(f"K = {K} must be a multiple of 4")
+    out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    if bias is not None:
+        bias = bias.float().contiguous()
+    rc = _lib.call(dev, "wgnn_linear_fwd", _ptr(x), x.stride(0), _ptr(weight), weight.stride(0), _ptr(bias), _ptr(out),
+                   out.stride(0), M, N, K, _lib.FLAG_RELU if relu else 0, _stream(dev))
+    _lib.check(rc, "wgnn_linear_fwd")
+    return out

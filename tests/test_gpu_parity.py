@@ -1024,3 +1024,52 @@ def test_full_size_cfg3_training_step_matches_cpu_autograd():
         want, got = p[k].grad.numpy(), q.grad.cpu().numpy()
         scale = np.abs(want).max()
         assert np.abs(got - want).max() < 2e-3 * scale + 1e-6, (k, np.abs(got - want).max(), scale)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 16, 4), (127, 200, 200), (128, 256, 400), (1000, 16, 256), (777, 132, 52), (4096, 256, 256)])
+@pytest.mark.parametrize("relu,with_bias", [(True, True), (False, False)])
+def test_linear_fwd_on_the_fp32_matrix_cores(M, N, K, relu, with_bias):
+    """wgnn_linear_fwd = NodeUpdate's relu(fc_neigh(.)) / the head (gnn.py:18-25,66-67) on v_mfma_f32_32x32x2_f32:
+    against an fp64 evaluation, edge tiles in every dimension, strided inputs."""
+    from scdeepsort_amd import ops
+    rng = np.random.default_rng(M + N + K)
+    xw = rng.standard_normal((M, K + 4)).astype(np.float32); w = rng.standard_normal((N, K)).astype(np.float32) / np.sqrt(K)
+    b = rng.standard_normal(N).astype(np.float32) if with_bias else None
+    x = dev(xw)[:, :K]                                            # leading dimension K + 4
+    out = ops.linear_fwd(x, dev(w), dev(b) if with_bias else None, relu=relu)
+    want = xw[:, :K].astype(np.float64) @ w.astype(np.float64).T + (b if with_bias else 0)
+    want = np.maximum(want, 0) if relu else want
+    np.testing.assert_allclose(out.cpu().numpy(), want, atol=2e-5)
+
+
+def test_agg_linear_relu_fused_entry_matches_reference_order():
+    """wgnn_agg_linear_relu_fwd (SURVEY 8b's optional fused entry): one reference layer on a block in the reference's
+    literal order - aggregate (gnn.py:47-56,65) then relu(fc_neigh(neigh)) (gnn.py:18-25) - through the C ABI only."""
+    from scdeepsort_amd import _lib
+    from scdeepsort_amd.graph import _ptr, _stream
+    c = small_case(cells=300, genes=120, dim=24, hidden=20, seed=17, density=0.2, test_cells=0)
+    G = c["G"]
+    sd = O.init_params(24, 20, 4, 1, G, seed=9)
+    g = sda.CellGeneGraph.from_expression(c["expr"], device=DEV, chunk=16)           # long-row splitting too
+    cg = O.build_csr_graph(c["expr"])
+    alpha = sd["alpha"].numpy().ravel()
+    zc, _ = O.csr_aggregate(cg, alpha, c["feats"][:G].astype(np.float64), c["feats"][G:].astype(np.float64), want_genes=False)
+    W, b = sd["layers.0.fc_neigh.weight"].numpy(), sd["layers.0.fc_neigh.bias"].numpy()
+    want = np.maximum(zc @ W.T.astype(np.float64) + b, 0)
+    x = dev(c["feats"]); d = torch.device(DEV)
+    csr, plan = g.cg, g.cg.plan
+    neigh = torch.empty(csr.n_rows, 24, device=DEV); out = torch.empty(csr.n_rows, 20, device=DEV)
+    part = torch.empty(max(1, plan.n_partials) * 24, device=DEV)
+    a_d, W_d, b_d = dev(alpha), dev(W), dev(b)
+    hs, hc = x[:G].contiguous(), x[G:].contiguous()
+    rc = _lib.call(d, "wgnn_agg_linear_relu_fwd", _ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), _ptr(a_d), sda.SRC_IS_GENE,
+                   G + 1, _ptr(hs), 24, _ptr(hc), 24, None, _ptr(csr.inv_deg), csr.n_rows, 24, 0,
+                   _ptr(plan.items), plan.n_items, _ptr(plan.long_rows) if plan.n_long else None, plan.n_long,
+                   _ptr(part), plan.n_partials, _ptr(neigh), _ptr(W_d), 24, _ptr(b_d), 20, 1, _ptr(out), 20, _stream(d))
+    assert rc == 0
+    np.testing.assert_allclose(neigh.cpu().numpy(), zc, atol=TOL)
+    np.testing.assert_allclose(out.cpu().numpy(), want, atol=TOL)
+    assert _lib.call(d, "wgnn_agg_linear_relu_fwd", _ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), _ptr(a_d), sda.SRC_IS_GENE,
+                     G + 1, _ptr(hs), 24, _ptr(hc), 24, None, _ptr(csr.inv_deg), csr.n_rows, 24, 0,
+                     _ptr(plan.items), plan.n_items, None, 0, None, 0, None, _ptr(W_d), 24, _ptr(b_d), 20, 1, _ptr(out), 20,
+                     _stream(d)) == -4                                             # missing scratch -> WGNN_ERR_WORKSPACE
