@@ -37,6 +37,7 @@ constexpr int kTileRows = kTW * kRPW;         // 256
 constexpr int kWStripBytes = kTW * 256;       // flat kernel: one 64-entry weight strip per wave
 // ablation switches (timing experiments only; results are wrong when set)
 constexpr unsigned kDbgNoFill = 1u << 16, kDbgNoCompute = 1u << 17, kDbgNoBarrier = 1u << 18;
+constexpr unsigned kDbgFillToVgpr = 1u << 20;      // the fill's loads go to scratch VGPRs instead of LDS: same VMEM issue / L2 traffic, no LDS writes
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -237,6 +238,20 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
         if (np == 0) return;
         const char* g = reinterpret_cast<const char*>(a.src) + ((size_t)r0 + wave) * g_row;
         const int l = (int)(size_t)smem + buf * buf_bytes + wave * row_bytes;
+        if (DBG && (dbg & kDbgFillToVgpr)) {                  // ablation: identical loads, no LDS writes
+#define WGNN_FILLV_NEXT(K)                                                                                  \
+        "s_cmp_lt_u32 %[np], " #K "\n\ts_cbranch_scc1 .Lw4_fv_%=\n\t"                                        \
+        "s_add_u32 s94, s94, 0x4000\n\ts_addc_u32 s95, s95, 0\n\t"                                          \
+        "global_load_dwordx4 v[40:43], %[vo], s[94:95]\n\t"
+            asm volatile("s_mov_b64 s[94:95], %[g]\n\t"
+                         "global_load_dwordx4 v[40:43], %[vo], s[94:95]\n\t"
+                         WGNN_FILLV_NEXT(2) WGNN_FILLV_NEXT(3) WGNN_FILLV_NEXT(4) WGNN_FILLV_NEXT(5)
+                         ".Lw4_fv_%=:"
+                         ::[g] "s"(g), [vo] "v"(lane16), [np] "s"(np)
+                         : "memory", "scc", "s94", "s95", "v40", "v41", "v42", "v43");
+#undef WGNN_FILLV_NEXT
+            return;
+        }
         // EXEC is narrowed to the D/4 lanes that carry data for the duration of the burst (a D < 256 row is shorter than
         // its 1 KiB LDS slot; the slot's tail is never read by a lane that is stored)
 #define WGNN_FILL_NEXT(K)                                                                                   \

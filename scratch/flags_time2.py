@@ -17,8 +17,8 @@ def timeit(f,n=10):
 kb=78
 tpc=g.cg.tile_plan(kb); tpg=g.gc.tile_plan(kb)
 B=lambda *bits: sum(1<<b for b in bits)
-for rep in range(2):
-  for nm,fl in [('full',0),('nofill',B(16)),('nobarrier(racy)',B(18)),('nofill+nobar',B(16,18)),('nocompute',B(17)),('nocompute+nobar',B(17,18)),('nocompute+nofill',B(17,16))]:
+for rep in range(1):
+  for nm,fl in [('full',0),('nofill',B(16)),('nobarrier(racy)',B(18)),('nofill+nobar',B(16,18)),('nocompute',B(17)),('nocompute+nobar',B(17,18)),('nocompute+nofill',B(17,16)),('fill->vgpr (no LDS writes)',B(20)),('fill->vgpr + nobar',B(20,18)),('fill->vgpr + nocompute',B(20,17))]:
     ops.DEBUG_FLAGS=fl
     tc=timeit(lambda: ops.agg_fwd_tiled(g.cg,tpc,alpha,sda.SRC_IS_GENE,G+1,hg,hc))
     tg=timeit(lambda: ops.agg_fwd_tiled(g.gc,tpg,alpha,sda.DST_IS_GENE,G,hc,hg))
