@@ -95,7 +95,8 @@ def test_fit_predict_roundtrip(tmp_path):
 
 
 @pytest.mark.gpu
-def test_fit_replays_minibatch_steps_as_hipgraphs(tmp_path):
+@pytest.mark.parametrize("n_layers", [1, 2])
+def test_fit_replays_minibatch_steps_as_hipgraphs(tmp_path, n_layers):
     """Default reference shape (n_layers = 1, train.py:145): full-size mini-batch steps are captured once and replayed
     (graphed.GraphedTrainStep) - same training outcome as the eager loop."""
     rng = np.random.default_rng(5)
@@ -106,8 +107,8 @@ def test_fit_replays_minibatch_steps_as_hipgraphs(tmp_path):
     d1, c1, _ = _write_dataset(tmp_path, "mouse_Demo1", 700, rng, genes, programs)
     hist = {}
     for graphed in (True, False):
-        clf = sda.DeepSortClassifier("mouse", "Demo", dense_dim=16, hidden_dim=12, batch_size=64, n_epochs=12, n_layers=1,
-                                     learning_rate=0.01, random_seed=4, gpu_id=0, dropout=0.0)
+        clf = sda.DeepSortClassifier("mouse", "Demo", dense_dim=16, hidden_dim=12, batch_size=64, n_epochs=12,
+                                     n_layers=n_layers, learning_rate=0.01, random_seed=4, gpu_id=0, dropout=0.0)
         clf.graph_steps = graphed
         clf.fit([(d1, c1)])
         hist[graphed] = clf.history
