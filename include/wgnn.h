@@ -231,6 +231,23 @@ int wgnn_normalize_rows(const int32_t* rowptr, const float* val_in, float* val_o
                         int64_t n_rows, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * K5  seeded neighbour subsampling (train.py:37-40,71-78: NeighborSampler(expand_factor = num_neighbors,
+ *     neighbor_type = 'in')): for each of n_rows destination rows (row_ids or 0..n_rows-1) draw min(k, deg + 1) of its
+ *     deg + 1 in-edges - the deg CSR entries plus the unit self-loop the reference's graph holds explicitly
+ *     (preprocess_internal.py:213-214) - uniformly without replacement.  Output in ELL form (static shapes):
+ *       out_col / out_val [n_rows * k] : row i owns [i*k, i*k + out_cnt[i]) (drawn real edges, parent col / val)
+ *       out_cnt  [n_rows]              : number of real edges drawn
+ *       out_self [n_rows]              : 1.0 where the self-loop was among the draws
+ *       out_inv  [n_rows]              : 1 / (number of drawn edges)   - fn.mean's divisor
+ *     Random numbers = hash(seed, *step, stream_id, row, draw): `step` is a DEVICE counter the caller advances on the
+ *     stream (a captured hipGraph therefore draws a new sample at every replay); no state is read back.  k <= 256.
+ * ------------------------------------------------------------------------- */
+int wgnn_sample_rows(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* row_ids,
+                     int64_t n_rows, int32_t k, uint64_t seed, const int64_t* step, int32_t stream_id,
+                     int32_t* out_col, float* out_val, int32_t* out_cnt, float* out_self, float* out_inv,
+                     void* stream);
+
+/* ---------------------------------------------------------------------------
  * Dense half of a layer on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: exact fp32, an fmaf chain in k order):
  *     out[M, N] = act( x[M, K] . w[N, K]^T + bias[N] )
  * = NodeUpdate.forward's `activation(fc_neigh(neigh))` (models/gnn.py:18-25; w / bias in nn.Linear's layout) and the

@@ -188,8 +188,13 @@ class DeepSortClassifier:
         best, self.history = -1.0, []
         sample_gen = None
         if self.num_neighbors:                                               # train.py:39-40,71-78
-            sample_gen = torch.Generator(device=dev)
-            sample_gen.manual_seed(self.random_seed if self.random_seed is not None else torch.initial_seed() % 2 ** 31)
+            from .sampler import DeviceSampler
+            seed = self.random_seed if self.random_seed is not None else torch.initial_seed() % 2 ** 31
+            if min(self.num_neighbors, max(graph.cg.max_row_nnz, graph.gc.max_row_nnz) + 1) <= 256:
+                sample_gen = DeviceSampler(seed, dev)                        # K5: static shapes, sync-free, capturable
+            else:                                                            # very wide draws: torch-op sampler
+                sample_gen = torch.Generator(device=dev)
+                sample_gen.manual_seed(seed)
         save_path = Path(save_path) if save_path is not None else None
         if save_path is not None:
             save_path.mkdir(parents=True, exist_ok=True)
@@ -213,9 +218,9 @@ class DeepSortClassifier:
             return loss.detach()
 
         step = train_step
-        if self.graph_steps and not self.num_neighbors and len(train_ids) >= 8 * self.batch_size:
-            # full-neighbourhood mini-batches have static shapes: one hipGraph launch per batch (graphed.py).  The
-            # neighbour-subsampled mode draws variable-size NodeFlows and stays eager.
+        static_shapes = not self.num_neighbors or not isinstance(sample_gen, torch.Generator)
+        if self.graph_steps and static_shapes and len(train_ids) >= 8 * self.batch_size:
+            # static shapes (full neighbourhoods, or NodeFlows drawn by the device sampler): one hipGraph launch per batch
             from .graphed import GraphedTrainStep
             step = GraphedTrainStep(train_step, self.batch_size, dev)
         self._step = step

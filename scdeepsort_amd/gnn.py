@@ -204,17 +204,22 @@ class GNN(nn.Module):
                 generator: Optional[torch.Generator] = None, nodeflow=None) -> torch.Tensor:
         """Logits ``[len(seeds), n_classes]`` (all cells in order when ``seeds`` is None); no softmax (gnn.py:66-68).
 
-        ``num_neighbors > 0`` draws a NodeFlow with at most that many in-edges per node (train.py:37-40, seeded by
-        ``generator``); 0 / None = every in-edge, the reference's default and its eval / predict mode."""
+        ``num_neighbors > 0`` draws a NodeFlow with at most that many in-edges per node (train.py:37-40); ``generator`` is
+        a ``sampler.DeviceSampler`` (K5 ``wgnn_sample_rows``: static shapes, sync-free, hipGraph-capturable) or a
+        ``torch.Generator`` (torch-op sampler with data-dependent shapes); 0 / None = every in-edge, the reference's
+        default and its eval / predict mode."""
         if features is None:
             features = getattr(g, "features", None)
             if features is None:
                 raise ValueError("pass features or set graph.features")
         if nodeflow is None and num_neighbors:
-            from .sampler import sample_nodeflow
+            from .sampler import DeviceSampler, sample_nodeflow, sample_nodeflow_static
             cells = (seeds.to(g.device) - self.gene_num) if seeds is not None \
                 else torch.arange(g.num_cells, device=g.device)
-            nodeflow = sample_nodeflow(g, cells, self.n_layers, int(num_neighbors), generator)
+            if isinstance(generator, DeviceSampler):        # K5: static shapes, no host synchronisation, capturable
+                nodeflow = sample_nodeflow_static(g, cells, self.n_layers, int(num_neighbors), generator)
+            else:
+                nodeflow = sample_nodeflow(g, cells, self.n_layers, int(num_neighbors), generator)
         if nodeflow is not None:
             return self.linear(self.embed_sampled(g, features, nodeflow))
         return self.linear(self.embed(g, features, seeds))

@@ -112,7 +112,7 @@ def device_plan(rowptr32: torch.Tensor, n_rows: int, max_row_nnz: int, chunk: in
     S = ceil(max_row_nnz / chunk) of items cut at multiples of ``chunk`` (later items of short rows are empty); S > 1
     rows fold their S partial sums in ``agg_finalize``.  ``max_row_nnz`` is a host-known BOUND on the row length."""
     dev = rowptr32.device
-    chunk = max(1, int(chunk))
+    chunk = max(1, int(chunk), -(-int(max_row_nnz) // 8))     # at most 8 items per row, whatever the bound
     S = max(1, -(-int(max_row_nnz) // chunk))
     beg, ln = rowptr32[:-1], rowptr32[1:] - rowptr32[:-1]
     s = torch.arange(S, device=dev, dtype=torch.int32).unsqueeze(0)
@@ -142,6 +142,10 @@ class AggCsr:
     rowptr_host: Optional[np.ndarray]    # None for blocks built on the device (sampler): then ``row_nnz_bound`` is set
     _t: Optional["AggCsr"] = field(default=None, repr=False)
     _tile_plan: Optional[object] = field(default=None, repr=False)
+    # ELL-padded block drawn by the device sampler (sampler.sample_block_static): row i owns col/val[i*ell_k, i*ell_k +
+    # ell_cnt[i]); rowptr holds the slot starts, the plan's items carry the real ranges.  Row-wave kernels only.
+    ell_k: int = 0
+    ell_cnt: Optional[torch.Tensor] = field(default=None, repr=False)
 
     @property
     def nnz(self) -> int:
@@ -153,6 +157,19 @@ class AggCsr:
 
     def transposed(self) -> "AggCsr":
         """Source-major copy: row s lists the destinations it feeds, values re-ordered (for K2)."""
+        if self._t is None and self.ell_cnt is not None:
+            # drawn block in ELL form: sort the valid entries by source behind a sentinel key (static shapes, no sync)
+            dev, n, kk = self.device, self.n_rows, self.ell_k
+            j = torch.arange(n * kk, device=dev)
+            owner = torch.div(j, kk, rounding_mode="floor")
+            valid = (j - owner * kk) < self.ell_cnt.long()[owner]
+            key = torch.where(valid, self.col.long(), torch.full_like(j, self.n_cols))
+            skey, perm = torch.sort(key, stable=True)
+            t_rowptr32 = torch.searchsorted(skey, torch.arange(self.n_cols + 1, device=dev)).to(torch.int32)
+            t_val = torch.where(valid[perm], self.val[perm], torch.zeros((), device=dev)).contiguous()
+            self._t = AggCsr(t_rowptr32, owner[perm].to(torch.int32).contiguous(), t_val, torch.empty(0, device=dev),
+                             self.n_cols, n, device_plan(t_rowptr32, self.n_cols, max(1, n), max(1, n)), None)   # one item per source
+            self._t._max_row_nnz = max(1, n)
         if self._t is None:
             dev = self.device
             counts = torch.bincount(self.col.long(), minlength=self.n_cols)
@@ -165,7 +182,7 @@ class AggCsr:
             t_val = self.val[order].contiguous()
             t_rowptr32 = t_rowptr.to(torch.int32)
             if self.rowptr_host is None:             # device-built block: a source feeds at most every row once
-                plan, host = device_plan(t_rowptr32, self.n_cols, max(1, self.n_rows), DEFAULT_CHUNK), None
+                plan, host = device_plan(t_rowptr32, self.n_cols, max(1, self.n_rows), max(1, self.n_rows)), None   # one item per source
             else:
                 host = t_rowptr32.cpu().numpy()
                 plan = build_plan(host, self.plan.chunk, device=dev)

@@ -50,6 +50,7 @@ def _dtype_code(t: torch.Tensor) -> int:
 PROFILE = None
 DEBUG_FLAGS = 0      # ablation switches of the tiled kernel (timing experiments only)
 # K1 dispatch: passes with nnz*D above this go to the LDS-streamed kernel (None = always row-wave)
+SEED_BLOCK_MAX_CAP = 32_000_000     # B x longest row above which a seed batch's backward walks the full transposed graph instead
 PAD_NARROW_TO_256 = False           # round-1 behaviour (hidden < 256 carried as 256 zero-padded columns); kept for A/B timing
 TILED_MIN_WORK = 500_000_000        # nnz*D above which the LDS-streamed kernels win (measured crossover: ~2 M edges at D = 256)
 
@@ -70,7 +71,7 @@ def agg_fwd(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, self_idx: int
     if D % 4:
         raise WgnnError(f"feature width {D} must be a multiple of 4")
     if (TILED_MIN_WORK is not None and row_ids is None and out is None and h_src.dtype == torch.float32
-            and (out_dtype in (None, torch.float32)) and D <= 256 and csr.nnz * D >= TILED_MIN_WORK):
+            and (out_dtype in (None, torch.float32)) and D <= 256 and csr.nnz * D >= TILED_MIN_WORK and csr.ell_cnt is None):
         return agg_fwd_tiled(csr, csr.tile_plan(tiled_block_rows(D)), alpha, mode, self_idx, h_src, h_self, bias=bias, relu=relu,
                              no_mean=no_mean)
     if h_self is not None:
@@ -136,7 +137,7 @@ def agg_bwd_src(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, g: torch.
         h_src = _rowmajor(h_src.float())
     if alpha is not None:
         alpha = alpha.reshape(-1).float().contiguous()
-    if TILED_MIN_WORK is not None and D <= 256 and csr.nnz * D >= TILED_MIN_WORK:
+    if TILED_MIN_WORK is not None and D <= 256 and csr.nnz * D >= TILED_MIN_WORK and csr.ell_cnt is None:
         # K2t: LDS-streamed kernel over the transposed structure; per-destination factors folded into g once
         tp = t.tile_plan(tiled_block_rows(D))
         scale = inv_deg if mode != DST_IS_GENE else inv_deg * alpha[: csr.n_rows]
@@ -206,7 +207,8 @@ def agg_bwd_alpha(csr: AggCsr, g: torch.Tensor, h_src: torch.Tensor, h_self: Opt
         h_self = _rowmajor(h_self.float())
     d_row = torch.empty(n_out, dtype=torch.float32, device=dev)
     d_self = torch.empty(n_out, dtype=torch.float32, device=dev) if h_self is not None else None
-    if (TILED_MIN_WORK is not None and row_ids is None and D <= 256 and csr.nnz * D >= TILED_MIN_WORK):
+    if (TILED_MIN_WORK is not None and row_ids is None and D <= 256 and csr.nnz * D >= TILED_MIN_WORK
+            and csr.ell_cnt is None):
         tp = csr.tile_plan(tiled_block_rows(D))                                   # K3t
         h_src = h_src.contiguous()
         part = torch.empty(tp.n_partials * D, dtype=torch.float32, device=dev) if tp.n_partials else None
@@ -319,15 +321,16 @@ class WeightedMeanAggregate(torch.autograd.Function):
         if need_src or want_src_dalpha:
             if rows is None:
                 dh_src = agg_bwd_src(csr, a if mode != NO_ALPHA else None, mode, g, h_src if want_src_dalpha else None, dalpha)
-            elif mode != DST_IS_GENE:
+            elif mode != DST_IS_GENE and rows.shape[0] * max(1, csr.max_row_nnz) <= SEED_BLOCK_MAX_CAP:
                 # seed mini-batch (train.py:71-87): K2 over the source-major view of just the batch's in-edges, built on
                 # the device with static shapes - no [n_rows, D] zero-padded gradient, no pass over the whole graph, no
                 # host synchronisation.  Repeated seeds are separate slots, so their gradients add up.
                 dh_src = agg_bwd_src_block(csr, row_ids, a if mode != NO_ALPHA else None, mode, g, inv_rows,
                                            h_src if want_src_dalpha else None, dalpha)
-            else:                                       # gene rows as a subset: not produced by GNN; generic route
+            else:                                       # gene rows as a subset (not produced by GNN) or a "batch" of most of the
+                                                        # graph (block capacity B x longest row too large): generic route
                 g_full = torch.zeros((csr.n_rows, D), dtype=torch.float32, device=dev).index_add_(0, rows, g)
-                dh_src = agg_bwd_src(csr, a, mode, g_full, None, dalpha)
+                dh_src = agg_bwd_src(csr, a if mode != NO_ALPHA else None, mode, g_full, h_src if want_src_dalpha else None, dalpha)
             dh_src = dh_src.to(h_src.dtype)
         dh_self = None
         hs_rows = None

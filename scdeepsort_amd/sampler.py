@@ -63,6 +63,66 @@ def sample_block(csr: AggCsr, rows: torch.Tensor, k: int, gen: Optional[torch.Ge
     return SampledBlock(rows, sub, self_drawn)
 
 
+class DeviceSampler:
+    """State of the sync-free sampler (``wgnn_sample_rows``): a seed and a DEVICE step counter.  Every drawn NodeFlow
+    advances the counter on the stream, so a captured training step draws a fresh sample at every replay."""
+
+    def __init__(self, seed: int, device):
+        self.seed = int(seed) & ((1 << 63) - 1)
+        self.step = torch.zeros(1, dtype=torch.int64, device=device)
+
+    def advance(self) -> None:
+        self.step += 1
+
+
+def sample_block_static(csr: AggCsr, rows: Optional[torch.Tensor], k: int, sampler: DeviceSampler, stream_id: int) -> SampledBlock:
+    """K5 (``wgnn_sample_rows``): draw min(k, deg+1) of the deg+1 in-edges of every row in ``rows`` (None = all rows) with
+    static output shapes and no host synchronisation.  The block is an ELL-padded ``AggCsr`` (``ell_k`` slots per row)."""
+    from . import _lib
+    from .graph import _ptr, _stream, Plan
+    dev = csr.device
+    kk = max(1, min(int(k), csr.max_row_nnz + 1))               # host-known bound on the draws per row (same draw law)
+    if kk > 256:
+        raise _lib.WgnnError("wgnn_sample_rows draws at most 256 edges per row")
+    if rows is None:
+        n, ids32, rows_l = csr.n_rows, None, torch.arange(csr.n_rows, device=dev)
+    else:
+        rows_l = rows.to(dev).long()
+        n, ids32 = rows_l.shape[0], rows_l.to(torch.int32).contiguous()
+    out_col = torch.zeros(max(1, n * kk), dtype=torch.int32, device=dev)
+    out_val = torch.zeros(max(1, n * kk), dtype=torch.float32, device=dev)
+    cnt = torch.zeros(n, dtype=torch.int32, device=dev)
+    self_drawn = torch.zeros(n, dtype=torch.float32, device=dev)
+    inv = torch.ones(n, dtype=torch.float32, device=dev)
+    _lib.check(_lib.call(dev, "wgnn_sample_rows", _ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), _ptr(ids32), n, kk,
+                         sampler.seed, _ptr(sampler.step), int(stream_id), _ptr(out_col), _ptr(out_val), _ptr(cnt),
+                         _ptr(self_drawn), _ptr(inv), _stream(dev)), "wgnn_sample_rows")
+    slot = torch.arange(n, device=dev, dtype=torch.int32)
+    items = torch.stack([slot, slot * kk, slot * kk + cnt, torch.full_like(slot, -1)], 1).contiguous()
+    starts = torch.arange(n + 1, device=dev, dtype=torch.int32) * kk
+    sub = AggCsr(starts, out_col[: n * kk], out_val[: n * kk], inv, n, csr.n_cols,
+                 Plan(items, torch.empty((0, 4), dtype=torch.int32, device=dev), 0, kk), None, ell_k=kk, ell_cnt=cnt)
+    sub._max_row_nnz = kk
+    return SampledBlock(rows_l, sub, self_drawn)
+
+
+def sample_nodeflow_static(g: CellGeneGraph, seed_cells: torch.Tensor, n_layers: int, k: int,
+                           sampler: DeviceSampler) -> "NodeFlow":
+    """NodeFlow with static shapes: the last block covers the seed cells; every lower block covers ALL cells and ALL
+    genes (each node draws its own <= k in-edges, exactly like the nodes a DGL NodeFlow would contain - the others are
+    simply never read).  O((G + C) k) work per layer instead of a data-dependent closure, no ``unique``, no host
+    synchronisation: a whole sampled training step can be captured in a hipGraph."""
+    blocks: List[Tuple[SampledBlock, Optional[SampledBlock]]] = []
+    for i in range(n_layers):
+        if i == n_layers - 1:
+            blocks.append((sample_block_static(g.cg, seed_cells, k, sampler, 2 * i), None))
+        else:
+            blocks.append((sample_block_static(g.cg, None, k, sampler, 2 * i),
+                           sample_block_static(g.gc, None, k, sampler, 2 * i + 1)))
+    sampler.advance()
+    return NodeFlow(blocks)
+
+
 @dataclass
 class NodeFlow:
     """blocks[i] = (cell block, gene block or None) feeding layer i+1; layer sets are implied by the blocks."""

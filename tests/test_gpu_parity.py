@@ -881,6 +881,29 @@ def test_api_classify_on_gpu_matches_oracle_postprocess(unsure_rate):
         assert (pred == -1).any() and (pred >= 0).any()
 
 
+def test_large_seed_batch_falls_back_to_the_full_transposed_graph():
+    """A "batch" whose block capacity (B x longest row) exceeds ops.SEED_BLOCK_MAX_CAP walks the full transposed graph
+    with a zero-padded gradient instead of building a seed block: same gradients (incl. alpha of the genes)."""
+    from scdeepsort_amd import ops
+    c = small_case(cells=80, genes=48, dim=16, hidden=12, n_classes=4, seed=15, test_cells=0)
+    sd = O.init_params(16, 12, 4, 1, 48, seed=6)
+    rg = O.build_reference_graph(c["expr"])
+    seeds = np.array([48 + i for i in (0, 5, 9, 33, 70, 3, 5)])
+    labels = torch.tensor([0, 1, 2, 3, 1, 0, 2])
+    loss, grads, _ = O.loss_and_grads(sd, rg, torch.from_numpy(c["feats"]), seeds, labels, 1)
+    g = sda.CellGeneGraph.from_expression(c["expr"], device=DEV)
+    saved, ops.SEED_BLOCK_MAX_CAP = ops.SEED_BLOCK_MAX_CAP, 0
+    try:
+        m = make_model(sd, 16, 12, 4, 1, 48)
+        l = F.cross_entropy(m(g, dev(c["feats"]), seeds=torch.from_numpy(seeds).to(DEV)), labels.to(DEV), reduction="sum")
+        l.backward()
+    finally:
+        ops.SEED_BLOCK_MAX_CAP = saved
+    assert l.item() == pytest.approx(float(loss), rel=1e-5)
+    for k, p in m.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), grads[k].numpy(), atol=2e-4, rtol=1e-3, err_msg=k)
+
+
 def test_repeated_seeds_accumulate_gradients():
     """A seed listed twice is two NodeFlow rows (train.py:71-81 would never draw that, but the operator must not lose
     a gradient - ADVICE r1): logits repeat, gradients add, both orders, vs the oracle's autograd on the same seed list."""
@@ -1073,3 +1096,133 @@ def test_agg_linear_relu_fused_entry_matches_reference_order():
                      G + 1, _ptr(hs), 24, _ptr(hc), 24, None, _ptr(csr.inv_deg), csr.n_rows, 24, 0,
                      _ptr(plan.items), plan.n_items, None, 0, None, 0, None, _ptr(W_d), 24, _ptr(b_d), 20, 1, _ptr(out), 20,
                      _stream(d)) == -4                                             # missing scratch -> WGNN_ERR_WORKSPACE
+
+
+# ------------------------------------------------------------------------------------------------
+# K5: device sampler with static shapes (wgnn_sample_rows)
+def _picker_from_static(nf, G):
+    table = {}
+    for b, (cb, gb) in enumerate(nf.blocks):
+        for blk, is_cell in ((cb, True), (gb, False)):
+            if blk is None:
+                continue
+            rows = blk.rows.cpu().numpy(); kk = blk.csr.ell_k
+            cnt = blk.csr.ell_cnt.cpu().numpy(); col = blk.csr.col.cpu().numpy().astype(np.int64)
+            sd = blk.self_drawn.cpu().numpy()
+            for j, r in enumerate(rows):
+                me = int(r) + (G if is_cell else 0)
+                src = col[j * kk: j * kk + cnt[j]] + (0 if is_cell else G)
+                table[(b, me)] = np.concatenate([src, [me]]) if sd[j] > 0 else src
+    return lambda block, v: table[(block, v)]
+
+
+@pytest.mark.parametrize("k,n_layers", [(1, 1), (3, 1), (8, 1), (3, 2), (8, 2), (70, 2)])
+def test_device_sampled_nodeflow_matches_oracle_on_same_sample(k, n_layers):
+    """num_neighbors > 0 (train.py:37-40,71-78) through K5 + K1/K2/K3: logits and all gradients against the oracle
+    replaying exactly the drawn sample; draw counts = min(k, in-degree incl. the self-loop); no edge drawn twice."""
+    from scdeepsort_amd.sampler import DeviceSampler, sample_nodeflow_static
+    c = small_case(cells=90, genes=40, dim=16, hidden=12, n_classes=4, seed=31, test_cells=0)
+    G = c["G"]
+    sd = O.init_params(16, 12, 4, n_layers, G, seed=8)
+    rg = O.build_reference_graph(c["expr"])
+    g = sda.CellGeneGraph.from_expression(c["expr"], device=DEV)
+    m = make_model(sd, 16, 12, 4, n_layers, G).train()
+    seeds = np.array([G + i for i in (4, 0, 17, 63, 88, 3, 41)])
+    labels = torch.tensor([0, 1, 2, 3, 1, 0, 2])
+    smp = DeviceSampler(100 + k, torch.device(DEV))
+    nf = sample_nodeflow_static(g, torch.from_numpy(seeds - G).to(DEV), n_layers, k, smp)
+    assert int(smp.step) == 1
+    for cb, gb in nf.blocks:
+        for blk, parent in ((cb, g.cg), (gb, g.gc)):
+            if blk is None:
+                continue
+            full = (parent.rowptr[1:] - parent.rowptr[:-1]).long()[blk.rows] + 1
+            drawn = blk.csr.ell_cnt.long() + blk.self_drawn.long()
+            assert torch.equal(drawn, torch.clamp(full, max=k))
+            np.testing.assert_allclose(blk.csr.inv_deg.cpu().numpy(), 1.0 / drawn.cpu().numpy(), rtol=1e-6)
+            kk, cnt, col = blk.csr.ell_k, blk.csr.ell_cnt.cpu().numpy(), blk.csr.col.cpu().numpy()
+            prp = parent.rowptr.cpu().numpy(); pcol = parent.col.cpu().numpy()
+            for j, r in enumerate(blk.rows.cpu().numpy()):
+                mine = col[j * kk: j * kk + cnt[j]]
+                assert len(set(mine.tolist())) == len(mine) and set(mine.tolist()) <= set(pcol[prp[r]:prp[r + 1]].tolist())
+    logits = m(g, dev(c["feats"]), nodeflow=nf)
+    loss = F.cross_entropy(logits, labels.to(DEV), reduction="sum")
+    loss.backward()
+    osd = {n: t.clone().requires_grad_(True) for n, t in sd.items()}
+    want = O.nodeflow_forward(osd, rg, torch.from_numpy(c["feats"]), seeds, n_layers, picker=_picker_from_static(nf, G))
+    oloss = F.cross_entropy(want, labels, reduction="sum")
+    oloss.backward()
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), want.detach().numpy(), atol=TOL)
+    for n, p in m.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), osd[n].grad.numpy(), atol=TOL * max(1.0, float(osd[n].grad.abs().max())),
+                                   err_msg=n)
+
+
+def test_device_sampler_is_uniform_seeded_and_advances():
+    """Floyd's draw on the device: every candidate of a row (its in-edges and the self-loop) is drawn with probability
+    k/m; the same (seed, step) reproduces the sample, the next step differs; k >= every degree = full neighbourhood."""
+    from scdeepsort_amd.sampler import DeviceSampler, sample_block_static
+    c = small_case(cells=60, genes=50, dim=8, seed=44, density=0.5, test_cells=0)
+    g = sda.CellGeneGraph.from_expression(c["expr"], device=DEV)
+    csr = g.cg
+    rp = csr.rowptr.cpu().numpy(); pcol = csr.col.cpu().numpy()
+    row = int(np.argmax(np.diff(rp)))                               # the longest row
+    deg = int(rp[row + 1] - rp[row]); m = deg + 1; k = 5
+    rows = torch.full((512,), row, device=DEV)                      # 512 independent draws of the same row per call
+    smp = DeviceSampler(7, torch.device(DEV))
+    hits = np.zeros(pcol.max() + 2); selfs = 0; n_draws = 0
+    first = None
+    for it in range(8):
+        blk = sample_block_static(csr, rows, k, smp, stream_id=0)
+        col = blk.csr.col.cpu().numpy().reshape(512, -1); cnt = blk.csr.ell_cnt.cpu().numpy()
+        if first is None:
+            first = col.copy()
+            assert (col == col[0]).all()                            # same (seed, step, stream, row) -> same draw
+        else:
+            assert it == 0 or not (col == first).all()
+        hits[col[0, :cnt[0]]] += 1; selfs += float(blk.self_drawn[0]); n_draws += 1
+        smp.advance()
+    # many steps on one row: empirical inclusion probability ~ k/m for every candidate
+    smp2 = DeviceSampler(11, torch.device(DEV))
+    freq = np.zeros(m)
+    one = torch.tensor([row], device=DEV)
+    pos = {int(cv): i for i, cv in enumerate(pcol[rp[row]:rp[row + 1]])}
+    N = 3000
+    for it in range(N):
+        blk = sample_block_static(csr, one, k, smp2, stream_id=3)
+        n = int(blk.csr.ell_cnt[0])
+        for cv in blk.csr.col[:n].cpu().numpy():
+            freq[pos[int(cv)]] += 1
+        freq[deg] += float(blk.self_drawn[0])
+        smp2.advance()
+    p = k / m
+    assert abs(freq.sum() / N - k) < 1e-9
+    assert np.abs(freq / N - p).max() < 5 * np.sqrt(p * (1 - p) / N) + 0.01
+    full = sample_block_static(csr, None, 10 ** 6, DeviceSampler(1, torch.device(DEV)), 0)
+    assert torch.equal(full.csr.ell_cnt.long(), (csr.rowptr[1:] - csr.rowptr[:-1]).long()) and bool((full.self_drawn == 1).all())
+
+
+def test_graphed_training_step_with_device_sampled_neighbours():
+    """A captured mini-batch step with num_neighbors > 0 draws a NEW sample at every replay (the sampler's step counter
+    lives on the device and is advanced inside the graph) and trains."""
+    from scdeepsort_amd.graphed import GraphedTrainStep
+    from scdeepsort_amd.sampler import DeviceSampler
+    c = small_case(cells=300, genes=80, dim=16, hidden=12, n_classes=4, seed=71, test_cells=0)
+    sd = O.init_params(16, 12, 4, 2, 80, seed=2)
+    g = sda.CellGeneGraph.from_expression(c["expr"], device=DEV)
+    x = dev(c["feats"])
+    y = (torch.arange(300, device=DEV) * 7 % 4).long()
+    model = make_model(sd, 16, 12, 4, 2, 80).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-2, capturable=True)
+    smp = DeviceSampler(3, torch.device(DEV))
+
+    def step(batch):
+        loss = F.cross_entropy(model(g, x, seeds=batch, num_neighbors=4, generator=smp), y[batch - 80], reduction="sum")
+        opt.zero_grad(set_to_none=True); loss.backward(); opt.step()
+        return loss.detach()
+    fn = GraphedTrainStep(step, 32, torch.device(DEV))
+    batch = torch.arange(80, 112, device=DEV)
+    losses = [float(fn(batch)) for _ in range(12)]
+    assert fn.replays == 9 and int(smp.step) == 12                 # the counter advanced inside every replay
+    assert len({round(l, 4) for l in losses}) > 6                  # different samples -> different losses
+    assert np.mean(losses[-3:]) < np.mean(losses[:3])
