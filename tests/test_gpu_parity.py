@@ -1226,3 +1226,40 @@ def test_graphed_training_step_with_device_sampled_neighbours():
     assert fn.replays == 9 and int(smp.step) == 12                 # the counter advanced inside every replay
     assert len({round(l, 4) for l in losses}) > 6                  # different samples -> different losses
     assert np.mean(losses[-3:]) < np.mean(losses[:3])
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_tile_kernel_fuzz_against_rowwave(seed):
+    """Randomised shapes / densities / widths / tile geometries / LDS block heights (hub genes, empty cells): the tile
+    kernel against the row-wave kernel (both already pinned to the oracle) - a guard for the hand-counted waitcnt /
+    computed-branch code paths that fixed-size tests may not reach."""
+    from scdeepsort_amd import ops
+    from scdeepsort_amd.graph import build_tile_plan
+    rng = np.random.default_rng(1000 + seed)
+    saved = ops.TILED_MIN_WORK
+    ops.TILED_MIN_WORK = None
+    try:
+        for it in range(12):
+            C = int(rng.integers(20, 2500)); G = int(rng.integers(10, 1200)); dens = float(rng.uniform(0.005, 0.4))
+            D = int(rng.choice([256, 256, 128, 64, 200, 4 * int(rng.integers(1, 65))]))
+            m = rng.random((C, G)) < dens
+            if rng.random() < 0.5:
+                m[:, rng.integers(0, G)] = True                              # a hub gene
+            if rng.random() < 0.5:
+                m[rng.integers(0, C), :] = False                             # an empty cell
+            x = sp.csr_matrix(np.where(m, rng.uniform(0.5, 7, (C, G)), 0).astype(np.float32))
+            if x.nnz == 0:
+                continue
+            g = sda.CellGeneGraph.from_expression(x, device=DEV)
+            alpha = torch.rand(G + 2, device=DEV) + 0.5
+            hg = torch.randn(G, D, device=DEV); hc = torch.randn(C, D, device=DEV)
+            kb = int(rng.integers(16, 79))
+            for csr, mode, si, hs, hself in ((g.cg, sda.SRC_IS_GENE, G + 1, hg, hc), (g.gc, sda.DST_IS_GENE, G, hc, hg)):
+                rt = int(rng.integers(1, 8)); cs = int(rng.integers(1, 6))
+                tp = build_tile_plan(csr, None if rng.random() < 0.3 else max(rt, -(-csr.n_rows // 256)), cs, block_rows=kb)
+                ref = ops.agg_fwd(csr, alpha, mode, si, hs, hself)
+                out = ops.agg_fwd_tiled(csr, tp, alpha, mode, si, hs, hself)
+                err = float((ref - out).abs().max())
+                assert err < TOL, (it, C, G, dens, D, kb, rt, cs, err)
+    finally:
+        ops.TILED_MIN_WORK = saved
