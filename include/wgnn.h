@@ -257,6 +257,15 @@ int wgnn_sample_rows(const int32_t* rowptr, const int32_t* col, const float* val
 int wgnn_linear_fwd(const float* x, int64_t ld_x, const float* w, int64_t ld_w, const float* bias,
                     float* out, int64_t ld_out, int64_t M, int32_t N, int32_t K, uint32_t flags, void* stream);
 
+/* Weight gradient of the same Linear (autograd of fc_neigh / linear, train.py:84):
+ *     dW[N, K] (+)= sum_m g[m, N] * x[m, K]
+ * The node axis M (1e5 at cfg3) is the reduction: it is cut into n_slabs slabs whose partial [N, K] products are folded in
+ * fixed order (deterministic).  Query n_slabs / workspace bytes with wgnn_linear_wgrad_workspace; N, K, ld_g, ld_x
+ * multiples of 4. */
+int wgnn_linear_wgrad_workspace(int64_t M, int32_t N, int32_t K, int64_t* n_slabs, int64_t* bytes);
+int wgnn_linear_wgrad(const float* g, int64_t ld_g, const float* x, int64_t ld_x, float* dW, int64_t ld_dw,
+                      int64_t M, int32_t N, int32_t K, int accumulate, float* workspace, int64_t n_slabs, void* stream);
+
 /* ---------------------------------------------------------------------------
  * One reference layer on a block in the reference's literal order (SURVEY 8b's optional fused entry):
  *     neigh = nf.block_compute(i, message_func, fn.mean('m','neigh'))   (models/gnn.py:47-56,65)  = wgnn_agg_fwd (f32)

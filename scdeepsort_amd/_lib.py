@@ -42,6 +42,8 @@ SIGNATURES = {
     "wgnn_normalize_rows": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "wgnn_sample_rows": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, C.c_uint64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "wgnn_linear_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _u32, _vp]),
+    "wgnn_linear_wgrad_workspace": (C.c_int, [_i64, _i32, _i32, _vp, _vp]),
+    "wgnn_linear_wgrad": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _int, _vp, _i64, _vp]),
     "wgnn_agg_linear_relu_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _int, _i32, _vp, _i64, _vp, _i64, _vp, _vp,
                                            _i64, _i32, _u32, _vp, _i64, _vp, _i64, _vp, _i64, _vp,
                                            _vp, _i64, _vp, _i32, _u32, _vp, _i64, _vp]),

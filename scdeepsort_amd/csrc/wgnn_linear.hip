@@ -14,6 +14,7 @@
 // 32 x 32, 64 accumulator VGPRs), K walked in slabs of 16 staged in LDS (row stride 17 floats: the per-lane fragment
 // reads `As[(row)*17 + k]` hit 32 distinct banks), next slab's global loads issued before the current slab's MFMAs,
 // two LDS buffers, one barrier per slab.  M, N, K need only be multiples of 4 (K) / 1 (M, N): edges are guarded.
+#include <algorithm>
 #include "wgnn_common.h"
 
 namespace {
@@ -122,7 +123,137 @@ __global__ void __launch_bounds__(kLinThreads) linear_mfma_f32(const LinArgs a) 
         }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Weight gradient of the dense half:  dW[N, K] = sum_m g[m, N] * x[m, K]   (autograd of fc_neigh, train.py:84).
+// The reduction runs over the NODE axis (1e5 rows at cfg3) and the output is small (256 x 400), so the M axis is cut into
+// `n_slabs` slabs: workgroup (tile, slab) accumulates one 128 x 128 output tile over its slab on the fp32 matrix cores and
+// writes a partial; `wgrad_reduce` folds the slabs in fixed order (deterministic, no atomics).  The library GEMM the
+// framework picks for this shape (MT32x256x64, no split along M) takes 0.9 ms at cfg3 = 22 TF.
+// ---------------------------------------------------------------------------------------------
+struct WgArgs {
+    const float* g; long ld_g;
+    const float* x; long ld_x;
+    float* partial;                // [n_slabs, N, K]
+    long M; int N; int K; int n_slabs; long slab_rows;
+};
+
+__global__ void __launch_bounds__(kLinThreads) wgrad_mfma_f32(const WgArgs a) {
+    __shared__ float As[2][kBM * kLd];           // g tile, stored [n][m]
+    __shared__ float Bs[2][kBN * kLd];           // x tile, stored [k][m]
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_k = (a.K + kBN - 1) / kBN, tiles_n = (a.N + kBM - 1) / kBM;
+    const int tile = blockIdx.x % (tiles_k * tiles_n), slab = blockIdx.x / (tiles_k * tiles_n);
+    const int n0 = (tile / tiles_k) * kBM, k0 = (tile % tiles_k) * kBN;
+    const long m_begin = (long)slab * a.slab_rows, m_end = min(a.M, m_begin + a.slab_rows);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // thread t moves 2 float4 of g and 2 of x per step of 16 rows: row t/32 (+8), columns (t%32)*4 .. +3
+    const int lm = t >> 5, lc = (t & 31) * 4;
+    float4 ga[2], xa[2];
+    auto gload = [&](long m0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long m = m0 + lm + 8 * i;
+            const bool in = m < m_end;
+            ga[i] = (in && n0 + lc < a.N) ? ld4(a.g + m * a.ld_g + n0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);   // N, K % 4 == 0
+            xa[i] = (in && k0 + lc < a.K) ? ld4(a.x + m * a.ld_x + k0 + lc) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float* pa = &As[buf][lc * kLd + lm + 8 * i];
+            pa[0] = ga[i].x; pa[kLd] = ga[i].y; pa[2 * kLd] = ga[i].z; pa[3 * kLd] = ga[i].w;
+            float* pb = &Bs[buf][lc * kLd + lm + 8 * i];
+            pb[0] = xa[i].x; pb[kLd] = xa[i].y; pb[2 * kLd] = xa[i].z; pb[3 * kLd] = xa[i].w;
+        }
+    };
+    const long nstep = (m_end - m_begin + kBK - 1) / kBK;
+    const int fr = lane & 31, fk = lane >> 5;
+    if (nstep > 0) {
+        gload(m_begin);
+        lstore(0);
+        __syncthreads();
+        for (long s = 0; s < nstep; ++s) {
+            const int buf = (int)(s & 1);
+            if (s + 1 < nstep) gload(m_begin + (s + 1) * kBK);
+            const float* pa = &As[buf][(wm * 64 + fr) * kLd + fk];
+            const float* pb = &Bs[buf][(wn * 64 + fr) * kLd + fk];
+#pragma unroll
+            for (int kk = 0; kk < kBK; kk += 2) {
+                const float a0 = pa[kk], a1 = pa[32 * kLd + kk];
+                const float b0 = pb[kk], b1 = pb[32 * kLd + kk];
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            if (s + 1 < nstep) lstore(buf ^ 1);
+            __syncthreads();
+        }
+    }
+    float* out = a.partial + (size_t)slab * a.N * a.K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = k0 + wn * 64 + j * 32 + fr;
+            if (col >= a.K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                if (row < a.N) out[(size_t)row * a.K + col] = acc[i][j][r];
+            }
+        }
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce(const float* __restrict__ partial, float* __restrict__ out, long ld_out,
+                                                    int N, int K, int n_slabs, int accumulate) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)N * K) return;
+    float s = 0.f;
+    for (int p = 0; p < n_slabs; ++p) s += partial[(size_t)p * N * K + i];
+    float* o = out + (i / K) * ld_out + (i % K);
+    *o = accumulate ? *o + s : s;
+}
+
 }  // namespace
+
+extern "C" int wgnn_linear_wgrad_workspace(int64_t M, int32_t N, int32_t K, int64_t* n_slabs, int64_t* bytes) {
+    if (M < 0 || N <= 0 || K <= 0 || !n_slabs || !bytes) return WGNN_ERR_BAD_ARG;
+    const long tiles = ((N + kBM - 1) / kBM) * ((K + kBN - 1) / kBN);
+    long s = (4L * 256 + tiles - 1) / tiles;                 // ~4 workgroups per CU
+    s = std::max(1L, std::min(s, (long)((M + 511) / 512)));      // but at least 512 rows per slab
+    *n_slabs = s;
+    *bytes = s * (int64_t)N * K * 4;
+    return WGNN_OK;
+}
+
+extern "C" int wgnn_linear_wgrad(const float* g, int64_t ld_g, const float* x, int64_t ld_x, float* dW, int64_t ld_dw,
+                                 int64_t M, int32_t N, int32_t K, int accumulate, float* workspace, int64_t n_slabs,
+                                 void* stream) {
+    if (!g || !x || !dW || M < 0 || N <= 0 || K <= 0) return WGNN_ERR_BAD_ARG;
+    if (N % 4 || K % 4 || ld_g % 4 || ld_x % 4 || !aligned16(g) || !aligned16(x)) return WGNN_ERR_ALIGNMENT;
+    if (ld_g < N || ld_x < K || ld_dw < K) return WGNN_ERR_BAD_ARG;
+    if (!workspace || n_slabs <= 0) return WGNN_ERR_WORKSPACE;
+    const long tiles = ((N + kBM - 1) / kBM) * ((K + kBN - 1) / kBN);
+    const long slab_rows = std::max(1L, (long)((M + n_slabs - 1) / n_slabs));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    WgArgs a{g, (long)ld_g, x, (long)ld_x, workspace, (long)M, N, K, (int)n_slabs, ((slab_rows + kBK - 1) / kBK) * kBK};
+    hipLaunchKernelGGL(wgrad_mfma_f32, dim3((unsigned)(tiles * n_slabs)), dim3(kLinThreads), 0, st, a);
+    const long n = (long)N * K;
+    hipLaunchKernelGGL(wgrad_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, workspace, dW, (long)ld_dw, N, K,
+                       (int)n_slabs, accumulate);
+    return hipGetLastError() == hipSuccess ? WGNN_OK : WGNN_ERR_LAUNCH;
+}
 
 extern "C" int wgnn_linear_fwd(const float* x, int64_t ld_x, const float* w, int64_t ld_w, const float* bias,
                                float* out, int64_t ld_out, int64_t M, int32_t N, int32_t K, uint32_t flags, void* stream) {

@@ -110,7 +110,7 @@ def dropout_mask(shape, p: float, generator: Optional[torch.Generator], device, 
 def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local: torch.Tensor, ops: LocalOps,
                     n_layers: int, gather_logits: bool = True, shard_sizes: Optional[Sequence[int]] = None,
                     async_gather: bool = False, dropout_masks: Optional[Sequence[Tuple[torch.Tensor, torch.Tensor]]] = None,
-                    relu: bool = True):
+                    relu: bool = True, linear: Callable = torch.nn.functional.linear):
     """Layer-wise forward over a cell shard.  ``weights`` = list of (W_i, b_i) + (W_out, b_out) last.
     Features may be stored in fp16 (BASELINE cfg5): they are widened on the way into the fp32 projection, i.e. the
     arithmetic is "fp16-rounded inputs, fp32 accumulate".  ``shard_sizes`` (cells per rank, known at graph build)
@@ -126,8 +126,8 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
         if dropout_masks is not None:
             m_g, m_c = dropout_masks[i]
             h_g, h_c = h_g.to(m_g.dtype) * m_g, h_c.to(m_c.dtype) * m_c
-        p_g = torch.nn.functional.linear(h_g.to(W.dtype), W)
-        p_c = torch.nn.functional.linear(h_c.to(W.dtype), W)
+        p_g = linear(h_g.to(W.dtype), W)
+        p_c = linear(h_c.to(W.dtype), W)
         if last:
             h_c = ops.cells_layer(p_g, p_c, b, relu)
             break
@@ -188,14 +188,15 @@ def all_reduce_grads(params) -> None:
 
 
 def sharded_train_step(params, weights_fn, feats_g, feats_c_local, labels_local, ops: LocalOps, n_layers: int,
-                       optimizer, seeds_local: Optional[torch.Tensor] = None, dropout_masks=None, relu: bool = True) -> float:
+                       optimizer, seeds_local: Optional[torch.Tensor] = None, dropout_masks=None, relu: bool = True,
+                       linear: Callable = torch.nn.functional.linear) -> float:
     """One full-batch data-parallel training step over cell shards (BASELINE cfg4).
 
     loss = CrossEntropyLoss(reduction='sum') over this rank's cells (train.py:36); because the loss is a SUM, adding
     the per-rank parameter gradients (all_reduce_grads) reproduces the single-process gradient exactly, and every rank
     then applies the identical optimizer step.  Returns the global loss."""
     logits = sharded_forward(weights_fn(), None, feats_g, feats_c_local, ops, n_layers, gather_logits=False,
-                             dropout_masks=dropout_masks, relu=relu)
+                             dropout_masks=dropout_masks, relu=relu, linear=linear)
     if seeds_local is not None:
         logits = logits[seeds_local]
     loss = torch.nn.functional.cross_entropy(logits, labels_local, reduction="sum")

@@ -30,7 +30,7 @@ import torch.nn.functional as F
 
 from ._lib import DST_IS_GENE, SRC_IS_GENE
 from .graph import CellGeneGraph
-from .ops import weighted_mean_aggregate, weighted_sum
+from .ops import linear as _linear, weighted_mean_aggregate, weighted_sum
 
 
 class NodeUpdate(nn.Module):
@@ -110,9 +110,9 @@ class GNN(nn.Module):
 
         compact = cell_rows is not None
         if project_first:
-            p_g = F.linear(h_g, W)
+            p_g = _linear(h_g, W)
             need_all_cells = want_genes or not compact
-            p_c_all = F.linear(h_c, W) if need_all_cells else None
+            p_c_all = _linear(h_c, W) if need_all_cells else None
             p_c_self = p_c_all if not compact else (p_c_all[cell_rows.long()] if p_c_all is not None
                                                     else F.linear(h_c[cell_rows.long()], W))
             out_c = weighted_mean_aggregate(g.cg, self.alpha, SRC_IS_GENE, G + 1, p_g, p_c_self, bias=b,
@@ -125,12 +125,12 @@ class GNN(nn.Module):
         hc_self = h_c if not compact else h_c[cell_rows.long()]
         z_c = weighted_mean_aggregate(g.cg, self.alpha, SRC_IS_GENE, G + 1, h_g, hc_self, row_ids=cell_rows,
                                       self_compact=compact)
-        out_c = F.linear(z_c, W, b)
+        out_c = _linear(z_c, W, b)
         out_c = F.relu(out_c) if fuse_relu else out_c
         out_g = None
         if want_genes:
             z_g = weighted_mean_aggregate(g.gc, self.alpha, DST_IS_GENE, G, h_c, h_g)
-            out_g = F.linear(z_g, W, b)
+            out_g = _linear(z_g, W, b)
             out_g = finish(F.relu(out_g) if fuse_relu else out_g)
         return out_g, finish(out_c)
 

@@ -412,3 +412,55 @@ def linear_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
                    out.stride(0), M, N, K, _lib.FLAG_RELU if relu else 0, _stream(dev))
     _lib.check(rc, "wgnn_linear_fwd")
     return out
+
+
+WGRAD_MIN_ROWS = 16384       # from this many rows on, the weight gradient of a Linear runs through wgnn_linear_wgrad
+
+
+def linear_wgrad(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """``dW = g.T @ x`` ([N, K]) with ``wgnn_linear_wgrad``: split along the row (node) axis, fp32 matrix cores, partial
+    products folded in fixed order."""
+    import ctypes as C
+    dev = _require_cuda(g, x)
+    g = _rowmajor(g.float()); x = _rowmajor(x.float())
+    M, N = g.shape
+    K = x.shape[1]
+    if x.shape[0] != M or N % 4 or K % 4:
+        raise WgnnError("linear_wgrad: g [M, N] and x [M, K] with N, K multiples of 4")
+    ns, nb = C.c_int64(), C.c_int64()
+    _lib.check(_lib.lib().wgnn_linear_wgrad_workspace(M, N, K, C.addressof(ns), C.addressof(nb)), "wgnn_linear_wgrad_workspace")
+    ws = torch.empty(max(1, nb.value // 4), dtype=torch.float32, device=dev)
+    dW = torch.empty((N, K), dtype=torch.float32, device=dev)
+    rc = _lib.call(dev, "wgnn_linear_wgrad", _ptr(g), g.stride(0), _ptr(x), x.stride(0), _ptr(dW), K, M, N, K, 0, _ptr(ws),
+                   ns.value, _stream(dev))
+    _lib.check(rc, "wgnn_linear_wgrad")
+    return dW
+
+
+class _LinearBigM(torch.autograd.Function):
+    """``F.linear`` whose weight gradient - a [N, K] product reduced over up to 1e5-1e6 node rows - runs through
+    ``wgnn_linear_wgrad`` instead of the library GEMM the framework picks for that shape (0.9 ms = 22 TF at cfg3)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        dx = g @ weight if ctx.needs_input_grad[0] else None
+        dw = linear_wgrad(g, x).to(weight.dtype) if ctx.needs_input_grad[1] else None
+        db = g.sum(0) if ctx.has_bias and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``F.linear`` for the model's projections; in training on many rows the weight gradient uses the matrix-core kernel."""
+    if (torch.is_grad_enabled() and weight.requires_grad and x.is_cuda and x.dim() == 2 and x.shape[0] >= WGRAD_MIN_ROWS
+            and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.shape[0] % 4 == 0
+            and weight.shape[1] % 4 == 0):
+        return _LinearBigM.apply(x, weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)

@@ -15,7 +15,7 @@ from . import dist as D
 from ._lib import DST_IS_GENE, NO_ALPHA, SRC_IS_GENE
 from .gnn import GNN, _is_relu, pad_width
 from .graph import AggCsr, CellGeneGraph, _normalize_on_device, build_plan
-from .ops import agg_fwd, weighted_mean_aggregate, weighted_sum
+from .ops import agg_fwd, linear as _linear, weighted_mean_aggregate, weighted_sum
 
 
 class ShardedWgnn:
@@ -161,7 +161,7 @@ class ShardedWgnn:
         if dropout_masks is None:
             dropout_masks = self.dropout_masks(feats_g, feats_c_local)
         return D.sharded_train_step(list(self.model.parameters()), self._weights, feats_g, feats_c_local, labels_local,
-                                    self._ops(), self.model.n_layers, optimizer, seeds_local, dropout_masks, self.relu)
+                                    self._ops(), self.model.n_layers, optimizer, seeds_local, dropout_masks, self.relu, _linear)
 
     def forward(self, feats_g: torch.Tensor, feats_c_local: torch.Tensor, gather_logits: bool = True,
                 async_gather: bool = False) -> torch.Tensor:
@@ -173,7 +173,7 @@ class ShardedWgnn:
             return m.linear(m.embed(self.graph, (feats_g, feats_c_local)))
         self.wait_gather()
         res = D.sharded_forward(self._weights(), None, feats_g, feats_c_local, self._ops(), m.n_layers, gather_logits,
-                                self.shard_sizes, async_gather, self.dropout_masks(feats_g, feats_c_local), self.relu)
+                                self.shard_sizes, async_gather, self.dropout_masks(feats_g, feats_c_local), self.relu, _linear)
         if async_gather:
             res, self._pending = res
         return res

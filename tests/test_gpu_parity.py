@@ -1263,3 +1263,26 @@ def test_tile_kernel_fuzz_against_rowwave(seed):
                 assert err < TOL, (it, C, G, dens, D, kb, rt, cs, err)
     finally:
         ops.TILED_MIN_WORK = saved
+
+
+@pytest.mark.parametrize("M,N,K", [(20000, 256, 400), (16400, 200, 52), (70001, 16, 256), (513, 4, 4)])
+def test_linear_weight_gradient_on_the_matrix_cores(M, N, K):
+    """wgnn_linear_wgrad: dW = g^T x reduced over the node axis in slabs (fixed-order fold), against fp64; and
+    ops.linear's autograd (dx, dW, db) against torch's own Linear."""
+    from scdeepsort_amd import ops
+    rng = np.random.default_rng(M)
+    g = rng.standard_normal((M, N)).astype(np.float32); x = rng.standard_normal((M, K)).astype(np.float32)
+    dW = ops.linear_wgrad(dev(g), dev(x))
+    want = g.astype(np.float64).T @ x.astype(np.float64)
+    np.testing.assert_allclose(dW.cpu().numpy(), want, atol=2e-3 * np.sqrt(M / 20000), rtol=1e-4)
+    assert torch.equal(dW, ops.linear_wgrad(dev(g), dev(x)))                       # deterministic
+    if M >= ops.WGRAD_MIN_ROWS:
+        xs = [dev(x).requires_grad_(True) for _ in range(2)]
+        Ws = [dev(rng.standard_normal((N, K)).astype(np.float32) * 0.05).requires_grad_(True)]; Ws.append(Ws[0].detach().clone().requires_grad_(True))
+        bs = [dev(rng.standard_normal(N).astype(np.float32)).requires_grad_(True)]; bs.append(bs[0].detach().clone().requires_grad_(True))
+        up = dev(g)
+        (ops.linear(xs[0], Ws[0], bs[0]) * up).sum().backward()
+        (F.linear(xs[1], Ws[1], bs[1]) * up).sum().backward()
+        np.testing.assert_allclose(Ws[0].grad.cpu().numpy(), Ws[1].grad.cpu().numpy(), atol=2e-3 * np.sqrt(M / 20000), rtol=1e-4)
+        np.testing.assert_allclose(xs[0].grad.cpu().numpy(), xs[1].grad.cpu().numpy(), atol=1e-5)
+        np.testing.assert_allclose(bs[0].grad.cpu().numpy(), bs[1].grad.cpu().numpy(), atol=1e-3, rtol=1e-5)
