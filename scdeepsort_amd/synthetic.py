@@ -35,6 +35,7 @@ class Config:
 
 CONFIGS = {
     "tiny": Config("tiny", 512, 256, 32, dense_dim=40),
+    "tiny_atlas": Config("tiny_atlas", 3_001, 256, 32, dense_dim=40, feature_dtype=torch.float16, total_cells=True),   # cfg5's shape in small
     "cfg2": Config("cfg2", 10_000, 5_000, 128),
     "cfg3": Config("cfg3", 100_000, 20_000, 256),
     "cfg5": Config("cfg5", 764_741, 20_000, 256, feature_dtype=torch.float16, total_cells=True),

@@ -164,6 +164,21 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert line["config"]["cells_total"] == 20_000 and line["cpu_baseline"] is None
 
 
+def test_bench_strong_scaling_config_shards_the_job(tmp_path):
+    """cfg5's mode (`total_cells`: ONE job of fixed size split over the ranks, fp16-stored features) at a small size:
+    ragged shards (3001 cells over 2 ranks), `scaling: strong`, the per-rank records add up to the job."""
+    env = dict(os.environ, WGNN_BENCH_SHARE_GPU="1", WGNN_BENCH_CONFIG="tiny_atlas")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["cells_total"] == 3001
+    assert sorted(p["cells"] for p in line["roofline"]["per_gpu"]) == [1500, 1501]
+    assert "fp16" in line["dtype"]
+
+
 def test_bench_refuses_more_ranks_than_gpus():
     n = torch.cuda.device_count()
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "WGNN_BENCH_SHARE_GPU")}
