@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define WGNN_VERSION 100           /* 0.1.0 */
+#define WGNN_VERSION 101           /* 0.1.1: neigh_sum output of the forward operators, K5, dense entries */
 
 /* error codes */
 #define WGNN_OK                 0
@@ -118,13 +118,17 @@ int wgnn_plan_build_host_i64(const int64_t* rowptr_host, const int32_t* row_ids_
  *
  *   items/long_rows come from wgnn_plan_build_host (device copies).  `partials`
  *   must hold n_partials*D floats (may be NULL when n_long == 0).
+ *   neigh_sum (optional, f32 [n_out, D] contiguous, NULL to skip): receives sum_j val_j*[alpha[col_j]*]h_src[col_j] per
+ *   slot BEFORE the row factor / self-loop / mean / bias / ReLU.  Training saves it for DST_IS_GENE rows: the
+ *   gradient of alpha[r] is then inv_deg[r]*<g[r], neigh_sum[r]> - a row dot product instead of a second pass over the
+ *   edges (K3).
  * ------------------------------------------------------------------------- */
 int wgnn_agg_fwd(const int32_t* rowptr, const int32_t* col, const float* val,
                  const float* alpha, int alpha_mode, int32_t self_idx,
                  const void* h_src, int64_t ld_src,
                  const void* h_self, int64_t ld_self,
                  const int32_t* row_ids, const float* inv_deg, const float* bias,
-                 void* out, int64_t ld_out,
+                 void* out, int64_t ld_out, float* neigh_sum,
                  int64_t n_out, int32_t D, int dtype_in, int dtype_out, uint32_t flags,
                  const int32_t* items, int64_t n_items,
                  const int32_t* long_rows, int64_t n_long,
@@ -152,7 +156,7 @@ int wgnn_agg_fwd_tiled(const int32_t* rowptr, const float* alpha, int alpha_mode
                        const float* h_src, int64_t n_src, float* src_scratch,
                        const float* h_self, int64_t ld_self,
                        const int32_t* row_ids, const float* inv_deg, const float* bias,
-                       float* out, int64_t ld_out, int64_t n_out, int32_t D, uint32_t flags,
+                       float* out, int64_t ld_out, float* neigh_sum, int64_t n_out, int32_t D, uint32_t flags,
                        const int32_t* entries, const int32_t* seg_ptr, int32_t nblk_max, int32_t block_rows,
                        const int32_t* tile_items, const int32_t* tile_hdr, int64_t n_tiles,
                        const int32_t* long_rows, int64_t n_long, float* partials, int64_t n_partials,

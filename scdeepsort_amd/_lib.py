@@ -25,10 +25,10 @@ SIGNATURES = {
     "wgnn_plan_build_host": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "wgnn_plan_build_host_i64": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
     "wgnn_agg_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _int, _i32, _vp, _i64, _vp, _i64, _vp, _vp, _vp,
-                               _vp, _i64, _i64, _i32, _int, _int, _u32,
+                               _vp, _i64, _vp, _i64, _i32, _int, _int, _u32,
                                _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "wgnn_agg_fwd_tiled": (C.c_int, [_vp, _vp, _int, _i32, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _vp,
-                                     _vp, _i64, _i64, _i32, _u32, _vp, _vp, _i32, _i32, _vp, _vp, _i64,
+                                     _vp, _i64, _vp, _i64, _i32, _u32, _vp, _vp, _i32, _i32, _vp, _vp, _i64,
                                      _vp, _i64, _vp, _i64, _vp]),
     "wgnn_agg_bwd_src_tiled": (C.c_int, [_vp, _int, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _int, _i64, _i32,
                                          _vp, _vp, _i32, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),

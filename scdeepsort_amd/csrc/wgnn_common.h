@@ -22,7 +22,7 @@ struct KArgs {
     const int* row_ids; const float* inv_deg; const float* bias;
     void* out; long ld_out;
     const float* g; long ld_g;                   // EPI_BWD_ALPHA: upstream gradient rows
-    float* aux1; float* aux2;                    // dalpha (BWD_SRC) / dalpha_row, dself_row (BWD_ALPHA)
+    float* aux1; float* aux2;                    // neigh_sum (FWD, optional) / dalpha (BWD_SRC) / dalpha_row, dself_row (BWD_ALPHA)
     int D; unsigned flags; int accumulate;
     const int4* items; long n_items;
     const int4* long_rows; long n_long;
@@ -79,6 +79,7 @@ __device__ __forceinline__ void epilogue(const KArgs& a, float4 (&acc)[NV], int 
             const int c0 = (k * LPR + l) * 4;
             if (writer && c0 < a.D) {
                 float4 o = acc[k];
+                if (a.aux1) st4(a.aux1 + (size_t)slot * a.D + c0, o);           // raw neighbour sum, saved for dalpha
                 o.x *= rs; o.y *= rs; o.z *= rs; o.w *= rs;
                 if (has_self) fma4(o, sc, ld4(selfp + c0));
                 if (a.bias) { const float4 b = ld4(a.bias + c0); o.x += b.x; o.y += b.y; o.z += b.z; o.w += b.w; }

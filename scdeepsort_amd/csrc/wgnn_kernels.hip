@@ -282,7 +282,7 @@ int wgnn_agg_fwd(const int32_t* rowptr, const int32_t* col, const float* val,
                  const float* alpha, int alpha_mode, int32_t self_idx,
                  const void* h_src, int64_t ld_src, const void* h_self, int64_t ld_self,
                  const int32_t* row_ids, const float* inv_deg, const float* bias,
-                 void* out, int64_t ld_out, int64_t n_out, int32_t D, int dtype_in, int dtype_out, uint32_t flags,
+                 void* out, int64_t ld_out, float* neigh_sum, int64_t n_out, int32_t D, int dtype_in, int dtype_out, uint32_t flags,
                  const int32_t* items, int64_t n_items, const int32_t* long_rows, int64_t n_long,
                  float* partials, int64_t n_partials, void* stream) {
     int rc = check_common(D, n_out, items, n_items, long_rows, n_long, partials, n_partials);
@@ -302,9 +302,10 @@ int wgnn_agg_fwd(const int32_t* rowptr, const int32_t* col, const float* val,
     a.cs1 = (alpha_mode == WGNN_SRC_IS_GENE) ? alpha : nullptr; a.cs2 = nullptr;
     a.src = h_src; a.ld_src = ld_src; a.alpha = alpha; a.mode = alpha_mode; a.self_idx = self_idx;
     a.self = h_self; a.ld_self = ld_self; a.row_ids = row_ids; a.inv_deg = inv_deg; a.bias = bias;
-    a.out = out; a.ld_out = ld_out; a.D = D; a.flags = flags;
+    a.out = out; a.ld_out = ld_out; a.D = D; a.flags = flags; a.aux1 = neigh_sum;
     a.items = reinterpret_cast<const int4*>(items); a.n_items = n_items;
     a.long_rows = reinterpret_cast<const int4*>(long_rows); a.n_long = n_long; a.partials = partials;
+    if (neigh_sum && !aligned16(neigh_sum)) return WGNN_ERR_ALIGNMENT;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (!in16 && !out16) return dispatch_width<float, float, EPI_FWD>(a, st);
     if (in16 && !out16)  return dispatch_width<__half, float, EPI_FWD>(a, st);

@@ -285,7 +285,7 @@ extern "C" int wgnn_agg_linear_relu_fwd(const int32_t* rowptr, const int32_t* co
     if (!neigh_scratch || !aligned16(neigh_scratch)) return WGNN_ERR_WORKSPACE;
     if (agg_flags & WGNN_FLAG_RELU) return WGNN_ERR_BAD_ARG;           // the activation belongs to the dense half here
     int rc = wgnn_agg_fwd(rowptr, col, val, alpha, alpha_mode, self_idx, h_src, ld_src, h_self, ld_self, row_ids, inv_deg,
-                          nullptr, neigh_scratch, D, n_out, D, WGNN_F32, WGNN_F32, agg_flags, items, n_items, long_rows,
+                          nullptr, neigh_scratch, D, nullptr, n_out, D, WGNN_F32, WGNN_F32, agg_flags, items, n_items, long_rows,
                           n_long, partials, n_partials, stream);
     if (rc) return rc;
     return wgnn_linear_fwd(neigh_scratch, D, W, ld_w, bias, out, ld_out, n_out, H, D, lin_flags, stream);

@@ -432,7 +432,7 @@ extern "C" int wgnn_agg_fwd_tiled(const int32_t* rowptr, const float* alpha, int
                                   const float* h_src, int64_t n_src, float* src_scratch,
                                   const float* h_self, int64_t ld_self,
                                   const int32_t* row_ids, const float* inv_deg, const float* bias,
-                                  float* out, int64_t ld_out, int64_t n_out, int32_t D, uint32_t flags,
+                                  float* out, int64_t ld_out, float* neigh_sum, int64_t n_out, int32_t D, uint32_t flags,
                                   const int32_t* entries, const int32_t* seg_ptr, int32_t nblk_max, int32_t block_rows,
                                   const int32_t* tile_items, const int32_t* tile_hdr, int64_t n_tiles,
                                   const int32_t* long_rows, int64_t n_long, float* partials, int64_t n_partials,
@@ -462,7 +462,8 @@ extern "C" int wgnn_agg_fwd_tiled(const int32_t* rowptr, const float* alpha, int
     a.rowptr = rowptr;
     a.src = src; a.ld_src = D; a.alpha = alpha; a.mode = alpha_mode; a.self_idx = self_idx;
     a.self = h_self; a.ld_self = ld_self; a.row_ids = row_ids; a.inv_deg = inv_deg; a.bias = bias;
-    a.out = out; a.ld_out = ld_out; a.D = D; a.flags = flags;
+    a.out = out; a.ld_out = ld_out; a.D = D; a.flags = flags; a.aux1 = neigh_sum;
+    if (neigh_sum && !aligned16(neigh_sum)) return WGNN_ERR_ALIGNMENT;
     a.long_rows = reinterpret_cast<const int4*>(long_rows); a.n_long = n_long; a.partials = partials;
     TArgs t{reinterpret_cast<const int2*>(entries), seg_ptr, reinterpret_cast<const int4*>(tile_items),
             reinterpret_cast<const int2*>(tile_hdr), nblk_max, block_rows};

@@ -50,6 +50,7 @@ def _dtype_code(t: torch.Tensor) -> int:
 PROFILE = None
 DEBUG_FLAGS = 0      # ablation switches of the tiled kernel (timing experiments only)
 # K1 dispatch: passes with nnz*D above this go to the LDS-streamed kernel (None = always row-wave)
+SAVE_NEIGH_SUM = True               # training: the forward of gene rows saves its raw neighbour sums (no K3 pass in backward)
 SEED_BLOCK_MAX_CAP = 32_000_000     # B x longest row above which a seed batch's backward walks the full transposed graph instead
 PAD_NARROW_TO_256 = False           # round-1 behaviour (hidden < 256 carried as 256 zero-padded columns); kept for A/B timing
 TILED_MIN_WORK = 500_000_000        # nnz*D above which the LDS-streamed kernels win (measured crossover: ~2 M edges at D = 256)
@@ -63,8 +64,9 @@ def agg_fwd(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, self_idx: int
             h_src: torch.Tensor, h_self: Optional[torch.Tensor], *, bias: Optional[torch.Tensor] = None,
             relu: bool = False, row_ids: Optional[torch.Tensor] = None, self_compact: bool = False,
             no_mean: bool = False, out_dtype: Optional[torch.dtype] = None,
-            out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """K1 ``wgnn_agg_fwd``: weighted mean of in-neighbours incl. the implicit self-loop."""
+            out: Optional[torch.Tensor] = None, neigh_sum: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """K1 ``wgnn_agg_fwd``: weighted mean of in-neighbours incl. the implicit self-loop.  ``neigh_sum`` (f32 [n_out, D],
+    contiguous) optionally receives the raw neighbour sum of every output row (saved by training for dalpha)."""
     dev = _require_cuda(h_src, h_self, alpha, bias, csr.col)
     h_src = _rowmajor(h_src)
     D = h_src.shape[1]
@@ -73,7 +75,7 @@ def agg_fwd(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, self_idx: int
     if (TILED_MIN_WORK is not None and row_ids is None and out is None and h_src.dtype == torch.float32
             and (out_dtype in (None, torch.float32)) and D <= 256 and csr.nnz * D >= TILED_MIN_WORK and csr.ell_cnt is None):
         return agg_fwd_tiled(csr, csr.tile_plan(tiled_block_rows(D)), alpha, mode, self_idx, h_src, h_self, bias=bias, relu=relu,
-                             no_mean=no_mean)
+                             no_mean=no_mean, neigh_sum=neigh_sum)
     if h_self is not None:
         h_self = _rowmajor(h_self)
         if h_self.dtype != h_src.dtype or h_self.shape[1] != D:
@@ -104,7 +106,7 @@ def agg_fwd(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, self_idx: int
     rc = _lib.call(dev, "wgnn_agg_fwd",
         _ptr(csr.rowptr), _ptr(csr.col), _ptr(csr.val), _ptr(alpha), mode, self_idx,
         _ptr(h_src), h_src.stride(0), _ptr(h_self), h_self.stride(0) if h_self is not None else 0,
-        _ptr(ids), _ptr(csr.inv_deg), _ptr(bias), _ptr(out), out.stride(0), n_out, D,
+        _ptr(ids), _ptr(csr.inv_deg), _ptr(bias), _ptr(out), out.stride(0), _ptr(neigh_sum), n_out, D,
         _dtype_code(h_src), _dtype_code(out), flags,
         _ptr(plan.items), plan.n_items, _ptr(plan.long_rows) if plan.n_long else None, plan.n_long,
         _ptr(part), plan.n_partials, _stream(dev))
@@ -240,7 +242,7 @@ def tiled_block_rows(D: int) -> int:
 
 def agg_fwd_tiled(csr: AggCsr, tplan, alpha: Optional[torch.Tensor], mode: int, self_idx: int,
                   h_src: torch.Tensor, h_self: Optional[torch.Tensor], *, bias: Optional[torch.Tensor] = None,
-                  relu: bool = False, no_mean: bool = False) -> torch.Tensor:
+                  relu: bool = False, no_mean: bool = False, neigh_sum: Optional[torch.Tensor] = None) -> torch.Tensor:
     """K1t ``wgnn_agg_fwd_tiled``: same result as :func:`agg_fwd`, source table streamed through LDS."""
     dev = _require_cuda(h_src, h_self, alpha, bias, csr.col)
     if h_src.dtype != torch.float32:
@@ -268,7 +270,7 @@ def agg_fwd_tiled(csr: AggCsr, tplan, alpha: Optional[torch.Tensor], mode: int, 
     rc = _lib.call(dev, "wgnn_agg_fwd_tiled",
         _ptr(csr.rowptr), _ptr(alpha), mode, self_idx,
         _ptr(h_src), h_src.shape[0], _ptr(scratch), _ptr(h_self), h_self.stride(0) if h_self is not None else 0,
-        None, _ptr(csr.inv_deg), _ptr(bias), _ptr(out), out.stride(0), csr.n_rows, D, flags,
+        None, _ptr(csr.inv_deg), _ptr(bias), _ptr(out), out.stride(0), _ptr(neigh_sum), csr.n_rows, D, flags,
         _ptr(tplan.entries), _ptr(tplan.seg_ptr), tplan.nblk_max, tplan.block_rows, _ptr(tplan.items), _ptr(tplan.hdr), tplan.n_tiles,
         _ptr(tplan.long_rows) if n_long else None, n_long, _ptr(part), tplan.n_partials, _stream(dev))
     _lib.check(rc, "wgnn_agg_fwd_tiled")
@@ -292,16 +294,22 @@ class WeightedMeanAggregate(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h_src, h_self, alpha, bias, csr: AggCsr, mode: int, self_idx: int, relu: bool,
                 row_ids, self_compact: bool):
+        # gene rows (DST_IS_GENE) in training: keep the raw neighbour sum S[r]; dalpha[r] = inv_deg[r]*<g[r], S[r]> is then
+        # a row dot product in backward instead of a second pass over all edges (K3)
+        nsum = None
+        if (mode == DST_IS_GENE and row_ids is None and ctx.needs_input_grad[2] and h_src.dtype == torch.float32
+                and SAVE_NEIGH_SUM):
+            nsum = torch.empty((csr.n_rows, h_src.shape[1]), dtype=torch.float32, device=h_src.device)
         out = agg_fwd(csr, alpha, mode, self_idx, h_src, h_self, bias=bias, relu=relu, row_ids=row_ids,
-                      self_compact=self_compact)
+                      self_compact=self_compact, neigh_sum=nsum)
         ctx.csr, ctx.mode, ctx.self_idx, ctx.relu, ctx.self_compact = csr, mode, self_idx, relu, self_compact
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(h_src, h_self, alpha, out if relu else None, row_ids)
+        ctx.save_for_backward(h_src, h_self, alpha, out if relu else None, row_ids, nsum)
         return out
 
     @staticmethod
     def backward(ctx, gout):
-        h_src, h_self, alpha, out, row_ids = ctx.saved_tensors
+        h_src, h_self, alpha, out, row_ids, nsum = ctx.saved_tensors
         csr: AggCsr = ctx.csr
         mode, self_idx = ctx.mode, ctx.self_idx
         g = gout.float()
@@ -344,7 +352,11 @@ class WeightedMeanAggregate(torch.autograd.Function):
                 else:
                     dh_self = torch.zeros_like(h_self).index_add_(0, rows, d)      # a repeated seed contributes twice
         if dalpha is not None and mode != NO_ALPHA:
-            if mode == DST_IS_GENE:
+            if mode == DST_IS_GENE and nsum is not None:
+                dalpha[: csr.n_rows] += (g * nsum).sum(1) * inv_rows
+                if hs_rows is not None:
+                    dalpha[self_idx] += ((g * hs_rows.float()).sum(1) * inv_rows).sum()
+            elif mode == DST_IS_GENE:
                 d_row, d_self = agg_bwd_alpha(csr, g, h_src, hs_rows, row_ids, self_compact=True if rows is not None else False)
                 if rows is None:
                     dalpha[: csr.n_rows] += d_row

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in wgnn.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in _lib.py"
-    assert lib.wgnn_version() == 100
+    assert lib.wgnn_version() == 101
     assert b"ok" == lib.wgnn_last_error_string(0)
 
 
@@ -48,7 +48,7 @@ def test_argument_validation_returns_error_codes_without_gpu():
     lib = _lib.lib()
     one = C.c_void_p(16)      # fake, aligned, never dereferenced: validation happens first
     def fwd(D=8, ld=8, mode=0, alpha=one, n_items=0, dtype=0):
-        return lib.wgnn_agg_fwd(one, one, one, alpha, mode, 0, one, ld, one, ld, None, None, None, one, ld, 4, D,
+        return lib.wgnn_agg_fwd(one, one, one, alpha, mode, 0, one, ld, one, ld, None, None, None, one, ld, None, 4, D,
                                 dtype, 0, 0, None, n_items, None, 0, None, 0, None)
     assert fwd(D=6) == -2                       # D % 4
     assert fwd(ld=6) == -2                      # ld % 4

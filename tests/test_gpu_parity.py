@@ -32,7 +32,7 @@ def test_library_loaded_and_gpu_present():
     assert torch.cuda.is_available()
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
     from scdeepsort_amd import _lib
-    assert _lib.lib().wgnn_version() == 100
+    assert _lib.lib().wgnn_version() == 101
 
 
 def test_kat_2x2_on_gpu():
@@ -147,9 +147,13 @@ def test_forward_seeds_match_nodeflow_batches():
     np.testing.assert_allclose(got, want, atol=TOL)
 
 
+@pytest.mark.parametrize("save_sum", [True, False])
 @pytest.mark.parametrize("n_layers,order", [(1, "auto"), (2, "project_first"), (2, "aggregate_first")])
-def test_training_gradients_match_autograd_oracle(n_layers, order):
-    """loss = CE_sum on a seed batch; grads of every parameter incl. alpha (train.py:34-36,80-84)."""
+def test_training_gradients_match_autograd_oracle(n_layers, order, save_sum, monkeypatch):
+    """loss = CE_sum on a seed batch; grads of every parameter incl. alpha (train.py:34-36,80-84).  `save_sum`: the gene
+    rows' alpha gradient from the neighbour sums saved by the forward (default) or from a K3 pass over the edges."""
+    from scdeepsort_amd import ops
+    monkeypatch.setattr(ops, "SAVE_NEIGH_SUM", save_sum)
     c = small_case(cells=80, genes=48, dim=16, hidden=12, n_classes=4, seed=15, test_cells=0)
     sd = O.init_params(16, 12, 4, n_layers, 48, seed=6)
     rg = O.build_reference_graph(c["expr"])
