@@ -25,6 +25,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="cfg3")
     ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--batch-size", type=int, default=0, help="global seed-batch size (0 = full batch); every rank "
+                    "takes batch/world seeds of its own shard per step (train.py:71-87, data-parallel)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = 0 if os.environ.get("WGNN_SHARE_GPU") == "1" else int(os.environ.get("LOCAL_RANK", 0))
@@ -52,16 +54,26 @@ def main():
     feats_g = S.synth_features(G, cfg.dense_dim, seed=7, device=dev)
     feats_c = S.synth_features(C, cfg.dense_dim, seed=100 + rank, device=dev)
     labels = (torch.arange(lo, hi, device=dev) * 2654435761 % cfg.n_classes).long()
-    loss = engine.train_step(feats_g, feats_c, labels, opt)          # warm-up (plans, communicator)
+    per_rank = args.batch_size // world if args.batch_size else 0
+    gen = torch.Generator(device=dev).manual_seed(1 + rank)
+
+    def one_step():
+        if not per_rank:
+            return engine.train_step(feats_g, feats_c, labels, opt)
+        sel = torch.randperm(C, device=dev, generator=gen)[:per_rank]             # this rank's seeds of the step
+        return engine.train_step(feats_g, feats_c, labels[sel], opt, seeds_local=sel)
+    loss = one_step()                                                # warm-up (plans, communicator)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = engine.train_step(feats_g, feats_c, labels, opt)
+        loss = one_step()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     if rank == 0:
-        print(f"{args.config}: {cfg.cells} cells over {world} rank(s): {dt * 1e3:.2f} ms per full-batch training step "
-              f"({cfg.cells / dt / 1e6:.2f} M cells/s), loss/cell {loss / cfg.cells:.4f}")
+        n_seed = per_rank * world if per_rank else cfg.cells
+        kind = f"mini-batch ({n_seed} seeds)" if per_rank else "full-batch"
+        print(f"{args.config}: {cfg.cells} cells over {world} rank(s): {dt * 1e3:.2f} ms per {kind} training step "
+              f"({n_seed / dt / 1e6:.2f} M cells/s), loss/cell {loss / n_seed:.4f}")
     if world > 1:
         dist.destroy_process_group()
 

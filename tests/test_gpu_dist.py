@@ -89,6 +89,22 @@ def _worker(rank, world, port, out_dir, hidden, dropout):
         assert abs(total - float(loss)) < 2e-4 * max(1.0, abs(float(loss))), (total, float(loss))
         for k, p_ in m.named_parameters():
             np.testing.assert_allclose(p_.grad.cpu().numpy(), p64[k].grad.numpy(), atol=3e-4, rtol=2e-3, err_msg=k)
+        # ---- a mini-batch step: every rank contributes the seeds of ITS shard (local indices); the summed loss and the
+        # all-reduced gradients equal the single-process loss over the union of the seeds (train.py:71-87 data-parallel)
+        if not dropout:
+            sel_local = torch.arange(0, hi - lo, 7, device=dev)
+            for p_ in m.parameters():
+                p_.grad = None
+            total_b = eng.train_step(feats[:G], feats[G + lo:G + hi], labels[lo:hi][sel_local], opt, seeds_local=sel_local)
+            sel_all = np.concatenate([np.arange(0, D.shard_range(C, r, world)[1] - D.shard_range(C, r, world)[0], 7)
+                                      + D.shard_range(C, r, world)[0] for r in range(world)])
+            pb = {k: v.detach().clone().double().requires_grad_(True) for k, v in sd.items()}
+            lg = O.nodeflow_forward(pb, rg, feats.cpu().double(), G + sel_all, 2)
+            lb = F.cross_entropy(lg, labels.cpu()[sel_all], reduction="sum")
+            lb.backward()
+            assert abs(total_b - float(lb)) < 2e-4 * max(1.0, abs(float(lb))), (total_b, float(lb))
+            for k, p_ in m.named_parameters():
+                np.testing.assert_allclose(p_.grad.cpu().numpy(), pb[k].grad.numpy(), atol=3e-4, rtol=2e-3, err_msg=k)
         # ---- the engine's own dropout streams: same gene mask on both ranks, different cell masks
         if dropout:
             m.train()
