@@ -94,7 +94,8 @@ def all_reduce_sum(x: torch.Tensor) -> torch.Tensor:
 @dataclass
 class LocalOps:
     """Local arithmetic of one shard (bound to the HIP operators in production)."""
-    cells_layer: Callable      # (p_g, p_c_local, bias, relu)              -> h_c_local'
+    cells_layer: Callable      # (p_g, p_c_local, bias, relu[, rows, self_compact]) -> h_c_local' (of `rows` only when given;
+                               #  self_compact: p_c_local already holds one row per entry of rows)
     genes_partial: Callable    # (p_c_local)                               -> partial [G, H] (plain weighted sum)
     genes_finish: Callable     # (partial_sum_global, p_g, bias, relu)     -> h_g'
 
@@ -110,7 +111,8 @@ def dropout_mask(shape, p: float, generator: Optional[torch.Generator], device, 
 def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local: torch.Tensor, ops: LocalOps,
                     n_layers: int, gather_logits: bool = True, shard_sizes: Optional[Sequence[int]] = None,
                     async_gather: bool = False, dropout_masks: Optional[Sequence[Tuple[torch.Tensor, torch.Tensor]]] = None,
-                    relu: bool = True, linear: Callable = torch.nn.functional.linear):
+                    relu: bool = True, linear: Callable = torch.nn.functional.linear,
+                    seeds_local: Optional[torch.Tensor] = None):
     """Layer-wise forward over a cell shard.  ``weights`` = list of (W_i, b_i) + (W_out, b_out) last.
     Features may be stored in fp16 (BASELINE cfg5): they are widened on the way into the fp32 projection, i.e. the
     arithmetic is "fp16-rounded inputs, fp32 accumulate".  ``shard_sizes`` (cells per rank, known at graph build)
@@ -120,30 +122,35 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
     ``dropout_masks[i] = (mask_genes [G,D_i], mask_cells_local [C_p,D_i])``: train-mode dropout on the input rows of
     layer i (gnn.py:60-64) - the gene mask must be identical on every rank (see :func:`dropout_mask`)."""
     h_g, h_c = feats_g, feats_c_local
+    compact = False                                     # h_c holds the seeds' rows only (see GNN.embed for the rule)
     for i in range(n_layers):
         W, b = weights[i]
         last = i == n_layers - 1
+        rows = seeds_local if (seeds_local is not None and i >= n_layers - 2) else None
         if dropout_masks is not None:
             m_g, m_c = dropout_masks[i]
+            if compact:
+                m_c = m_c[seeds_local.long()]
             h_g, h_c = h_g.to(m_g.dtype) * m_g, h_c.to(m_c.dtype) * m_c
         p_g = linear(h_g.to(W.dtype), W)
         p_c = linear(h_c.to(W.dtype), W)
-        if last:
-            h_c = ops.cells_layer(p_g, p_c, b, relu)
+        if last:                                        # a seed mini-batch only needs its own rows of the last layer
+            h_c = ops.cells_layer(p_g, p_c, b, relu) if rows is None else ops.cells_layer(p_g, p_c, b, relu, rows, compact)
             break
         part = ops.genes_partial(p_c)
         if torch.is_grad_enabled() and part.requires_grad:
-            new_c = ops.cells_layer(p_g, p_c, b, relu)
+            new_c = ops.cells_layer(p_g, p_c, b, relu) if rows is None else ops.cells_layer(p_g, p_c, b, relu, rows, False)
             part = all_reduce_sum(part)                 # differentiable: backward all-reduces dH1_g
         else:
             # the ONE data-path collective (X2, SURVEY 8e) runs on the communicator's stream while this rank's
             # cells<-genes pass (row-independent, no communication) computes
             work = dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=True) if world()[1] > 1 else None
-            new_c = ops.cells_layer(p_g, p_c, b, relu)
+            new_c = ops.cells_layer(p_g, p_c, b, relu) if rows is None else ops.cells_layer(p_g, p_c, b, relu, rows, False)
             if work is not None:
                 work.wait()                             # stream-level dependency on GPU backends, no host sync
         h_g = ops.genes_finish(part, p_g, b, relu)
         h_c = new_c
+        compact = rows is not None
     Wo, bo = weights[n_layers]
     logits = torch.nn.functional.linear(h_c, Wo, bo)
     rank, ws = world()
@@ -196,9 +203,7 @@ def sharded_train_step(params, weights_fn, feats_g, feats_c_local, labels_local,
     the per-rank parameter gradients (all_reduce_grads) reproduces the single-process gradient exactly, and every rank
     then applies the identical optimizer step.  Returns the global loss."""
     logits = sharded_forward(weights_fn(), None, feats_g, feats_c_local, ops, n_layers, gather_logits=False,
-                             dropout_masks=dropout_masks, relu=relu, linear=linear)
-    if seeds_local is not None:
-        logits = logits[seeds_local]
+                             dropout_masks=dropout_masks, relu=relu, linear=linear, seeds_local=seeds_local)
     loss = torch.nn.functional.cross_entropy(logits, labels_local, reduction="sum")
     optimizer.zero_grad()
     loss.backward()

@@ -82,8 +82,13 @@ class GNN(nn.Module):
         return pad_width(g.cg.nnz, H)
 
     def _layer(self, g: CellGeneGraph, layer: NodeUpdate, h_g: torch.Tensor, h_c: torch.Tensor,
-               want_genes: bool, cell_rows: Optional[torch.Tensor]):
+               want_genes: bool, cell_rows: Optional[torch.Tensor], h_c_compact: bool = False):
+        """One NodeFlow block for both node types.  ``cell_rows``: compute only these cell rows (a seed batch);
+        ``h_c_compact``: ``h_c`` already holds one row per entry of ``cell_rows`` (the previous layer was restricted to
+        the seeds) - then cells cannot be sources at this layer (``want_genes`` is False)."""
         G = self.gene_num
+        if h_c_compact and (want_genes or cell_rows is None):
+            raise ValueError("compact cell rows can only feed the seeds' own self-loop")
         W, b = layer.fc_neigh.weight, layer.fc_neigh.bias
         project_first = self.order == "project_first" or (self.order == "auto" and W.shape[0] <= W.shape[1])
         if h_g.shape[1] % 4:                               # e.g. dense_dim = 50: zero feature columns up to a multiple of 4
@@ -111,10 +116,13 @@ class GNN(nn.Module):
         compact = cell_rows is not None
         if project_first:
             p_g = _linear(h_g, W)
-            need_all_cells = want_genes or not compact
+            need_all_cells = (want_genes or not compact) and not h_c_compact
             p_c_all = _linear(h_c, W) if need_all_cells else None
-            p_c_self = p_c_all if not compact else (p_c_all[cell_rows.long()] if p_c_all is not None
-                                                    else F.linear(h_c[cell_rows.long()], W))
+            if h_c_compact:
+                p_c_self = F.linear(h_c, W)
+            else:
+                p_c_self = p_c_all if not compact else (p_c_all[cell_rows.long()] if p_c_all is not None
+                                                        else F.linear(h_c[cell_rows.long()], W))
             out_c = weighted_mean_aggregate(g.cg, self.alpha, SRC_IS_GENE, G + 1, p_g, p_c_self, bias=b,
                                             relu=fuse_relu, row_ids=cell_rows, self_compact=compact)
             out_g = None
@@ -122,7 +130,7 @@ class GNN(nn.Module):
                 out_g = weighted_mean_aggregate(g.gc, self.alpha, DST_IS_GENE, G, p_c_all, p_g, bias=b, relu=fuse_relu)
             return (finish(out_g) if out_g is not None else None), finish(out_c)
         # aggregate first (the reference's literal order: neigh -> fc_neigh -> activation)
-        hc_self = h_c if not compact else h_c[cell_rows.long()]
+        hc_self = h_c if (not compact or h_c_compact) else h_c[cell_rows.long()]
         z_c = weighted_mean_aggregate(g.cg, self.alpha, SRC_IS_GENE, G + 1, h_g, hc_self, row_ids=cell_rows,
                                       self_compact=compact)
         out_c = _linear(z_c, W, b)
@@ -148,9 +156,17 @@ class GNN(nn.Module):
         cell_rows = None
         if seeds is not None:
             cell_rows = (seeds.to(g.device) - G).to(torch.int32)
+        # Which cell rows a layer must produce: cells are never sources for cells, so below the last layer a cell's
+        # activation is read only (a) by the genes of the NEXT layer - all cells, as long as that layer computes genes -
+        # and (b) by the cell's own self-loop.  With a seed list, the second-to-last layer therefore needs the seeds'
+        # rows only (the last layer computes no genes): a 2-layer forward on a seed batch runs ONE full pass (layer-1
+        # genes) instead of two; the reference's NodeFlow closure contains exactly these nodes.
+        compact = False
         for i, layer in enumerate(self.layers):
             last = i == self.n_layers - 1
-            h_g, h_c = self._layer(g, layer, h_g, h_c, want_genes=not last, cell_rows=cell_rows if last else None)
+            rows = cell_rows if (cell_rows is not None and i >= self.n_layers - 2) else None
+            h_g, h_c = self._layer(g, layer, h_g, h_c, want_genes=not last, cell_rows=rows, h_c_compact=compact)
+            compact = rows is not None
         H = self.layers[-1].fc_neigh.weight.shape[0]
         return h_c if h_c.shape[1] == H else h_c[:, :H]
 

@@ -97,8 +97,11 @@ class ShardedWgnn:
         m, g = self.model, self.graph
         G = g.num_genes
 
-        def cells_layer(p_g, p_c, b, relu):
-            return weighted_mean_aggregate(g.cg, m.alpha, SRC_IS_GENE, G + 1, p_g, p_c, bias=b, relu=relu)
+        def cells_layer(p_g, p_c, b, relu, rows=None, self_compact=False):
+            if rows is None:
+                return weighted_mean_aggregate(g.cg, m.alpha, SRC_IS_GENE, G + 1, p_g, p_c, bias=b, relu=relu)
+            return weighted_mean_aggregate(g.cg, m.alpha, SRC_IS_GENE, G + 1, p_g, p_c if self_compact else p_c[rows.long()],
+                                           bias=b, relu=relu, row_ids=rows.to(torch.int32), self_compact=True)
 
         def genes_partial(p_c):
             if torch.is_grad_enabled() and p_c.requires_grad:

@@ -61,7 +61,7 @@ def _worker(rank, world, port, out_dir, cells=90):
         Acg, Agc = dense(A_cg), dense(A_gc)
         alpha = sd["alpha"].reshape(-1)
         ops = D.LocalOps(
-            cells_layer=lambda p_g, p_c, b, relu: torch.relu(((Acg @ (alpha[:G, None] * p_g)) + alpha[G + 1] * p_c) * inv_c[:, None] + b),
+            cells_layer=lambda p_g, p_c, b, relu, rows=None, sc=False: torch.relu(((Acg @ (alpha[:G, None] * p_g)) + alpha[G + 1] * p_c) * inv_c[:, None] + b),
             genes_partial=lambda p_c: Agc @ p_c,
             genes_finish=lambda part, p_g, b, relu: torch.relu((alpha[:G, None] * part + alpha[G] * p_g) * inv_g[:, None].double() + b))
         weights = [(sd[f"layers.{i}.fc_neigh.weight"], sd[f"layers.{i}.fc_neigh.bias"]) for i in range(2)] + \
@@ -107,7 +107,7 @@ def _worker(rank, world, port, out_dir, cells=90):
         params = {k: torch.nn.Parameter(v.clone()) for k, v in sd.items()}
         al = params["alpha"].reshape(-1)
         tops = D.LocalOps(
-            cells_layer=lambda p_g, p_c, b, relu: torch.relu(((Acg @ (al[:G, None] * p_g)) + al[G + 1] * p_c) * inv_c[:, None] + b),
+            cells_layer=lambda p_g, p_c, b, relu, rows=None, sc=False: torch.relu(((Acg @ (al[:G, None] * p_g)) + al[G + 1] * p_c) * inv_c[:, None] + b),
             genes_partial=lambda p_c: Agc @ p_c,
             genes_finish=lambda part, p_g, b, relu: torch.relu((al[:G, None] * part + al[G] * p_g) * inv_g[:, None].double() + b))
         wfn = lambda: [(params[f"layers.{i}.fc_neigh.weight"], params[f"layers.{i}.fc_neigh.bias"]) for i in range(2)] + \
