@@ -163,9 +163,9 @@ class AggCsr:
             j = torch.arange(n * kk, device=dev)
             owner = torch.div(j, kk, rounding_mode="floor")
             valid = (j - owner * kk) < self.ell_cnt.long()[owner]
-            key = torch.where(valid, self.col.long(), torch.full_like(j, self.n_cols))
+            key = torch.where(valid, self.col, torch.full_like(self.col, self.n_cols))       # int32 keys
             skey, perm = torch.sort(key, stable=True)
-            t_rowptr32 = torch.searchsorted(skey, torch.arange(self.n_cols + 1, device=dev)).to(torch.int32)
+            t_rowptr32 = torch.searchsorted(skey, torch.arange(self.n_cols + 1, device=dev, dtype=torch.int32)).to(torch.int32)
             t_val = torch.where(valid[perm], self.val[perm], torch.zeros((), device=dev)).contiguous()
             self._t = AggCsr(t_rowptr32, owner[perm].to(torch.int32).contiguous(), t_val, torch.empty(0, device=dev),
                              self.n_cols, n, device_plan(t_rowptr32, self.n_cols, max(1, n), max(1, n)), None)   # one item per source
@@ -259,11 +259,11 @@ class AggCsr:
         valid = j < off[-1] if B else torch.zeros_like(j, dtype=torch.bool)
         pos = j - (off[owner] - ln[owner])
         eidx = torch.where(valid, beg[owner] + pos, torch.zeros_like(j))
-        key = torch.where(valid, self.col[eidx].long(), torch.full_like(j, self.n_cols))
+        key = torch.where(valid, self.col[eidx], torch.full_like(self.col[eidx], self.n_cols))   # int32 keys: half the radix passes
         skey, perm = torch.sort(key, stable=True)                         # ties keep ascending slot order
         t_slot = owner[perm].to(torch.int32)
         t_val = torch.where(valid[perm], self.val[eidx[perm]], torch.zeros((), device=dev))
-        t_rowptr = torch.searchsorted(skey, torch.arange(self.n_cols + 1, device=dev)).to(torch.int32)
+        t_rowptr = torch.searchsorted(skey, torch.arange(self.n_cols + 1, device=dev, dtype=torch.int32)).to(torch.int32)
         rows = torch.arange(self.n_cols, device=dev, dtype=torch.int32)
         items = torch.stack([rows, t_rowptr[:-1], t_rowptr[1:], torch.full_like(rows, -1)], 1).contiguous()
         return t_rowptr, t_slot.contiguous(), t_val.contiguous(), items

@@ -51,7 +51,8 @@ PROFILE = None
 DEBUG_FLAGS = 0      # ablation switches of the tiled kernel (timing experiments only)
 # K1 dispatch: passes with nnz*D above this go to the LDS-streamed kernel (None = always row-wave)
 SAVE_NEIGH_SUM = True               # training: the forward of gene rows saves its raw neighbour sums (no K3 pass in backward)
-SEED_BLOCK_MAX_CAP = 32_000_000     # B x longest row above which a seed batch's backward walks the full transposed graph instead
+SEED_BLOCK_MAX_CAP = 12_000_000     # B x longest row above which a seed batch's backward walks the full transposed graph instead
+                                    # (sorting the padded block costs ~0.05 ms per million slots; the full K2t pass 1.2 ms at cfg3)
 PAD_NARROW_TO_256 = False           # round-1 behaviour (hidden < 256 carried as 256 zero-padded columns); kept for A/B timing
 TILED_MIN_WORK = 500_000_000        # nnz*D above which the LDS-streamed kernels win (measured crossover: ~2 M edges at D = 256)
 

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_train_r02
 rm -rf $OUT; mkdir -p $OUT
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o tr -- python $GRAFT_REPO_ROOT/examples/train_sharded.py --config cfg3 --steps 10 > $OUT/run.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o tr -- python $GRAFT_REPO_ROOT/examples/train_sharded.py --config cfg3 --steps 10 --batch-size 4096 > $OUT/run.log 2>&1
 tail -2 $OUT/run.log
 python - "$OUT" <<'PY'
 import csv, sys, glob, os
