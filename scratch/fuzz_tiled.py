@@ -19,7 +19,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 60):
     g=sda.CellGeneGraph.from_expression(x, device=dev)
     alpha=torch.rand(G+2,device=dev)+0.5
     hg=torch.randn(G,D,device=dev); hc=torch.randn(C,D,device=dev)
-    kb=int(rng.integers(16,79 if D==256 else 81))
+    kb=int(rng.integers(16,79))
     for csr,mode,si,hs,hself in ((g.cg,sda.SRC_IS_GENE,G+1,hg,hc),(g.gc,sda.DST_IS_GENE,G,hc,hg)):
         rt=int(rng.integers(1,8)); cs=int(rng.integers(1,6))
         tp=build_tile_plan(csr, None if rng.random()<0.3 else max(rt,-(-csr.n_rows//256)), cs, block_rows=kb)
