@@ -416,7 +416,7 @@ def _snake(p: torch.Tensor, n: int) -> torch.Tensor:
     return torch.where(r % 2 == 0, q, n - 1 - q)
 
 
-ONE_ROUND_MIN_NNZ = 20_000_000      # measured: 11.9 M edges even (0.24 vs 0.22 ms), 39.8 M -20 %, 79.8 M -14 %, 159.8 M -13 % (scratch/geom_rounds.py)
+ONE_ROUND_MIN_NNZ = 0               # one round wins or ties at every size measured: 2.0 M edges 62 vs 75 us, 11.9 M even, 39.8 M -20 %, 79.8 M -14 %, 159.8 M -13 % (scratch/geom_rounds.py, cfg2_crossover.py)
 
 
 def auto_tile_geometry(n_rows: int, n_cols: int, n_cus: int = 256, nnz: Optional[int] = None) -> Tuple[int, int]:
@@ -433,7 +433,8 @@ def auto_tile_geometry(n_rows: int, n_cols: int, n_cus: int = 256, nnz: Optional
         # destination row (written, then re-read by agg_finalize); at cfg3 the genes<-cells pass went from 80 x 16
         # tiles / 335 MB of partial sums / 1.42 ms to 85 x 3 / 63 MB / 1.22 ms (scratch/gene_pass_ab.py, round 2).
         splits = max(1, min(n_cus // n_row_tiles, n_cols // 512 or 1))
-        return max(n_row_tiles, n_cus // splits), splits               # fill the round: e.g. 82 -> 85 x 3 = 255 tiles
+        # fill the round with slightly smaller row tiles (82 -> 85 x 3 = 255 tiles), never by shredding a small operand
+        return max(n_row_tiles, min(n_cus // splits, -(-n_row_tiles * 115 // 100))), splits
     target = 5 * n_cus if nnz is None else min(5 * n_cus, max(160, nnz // 50_000))
     splits = max(1, min(round(target / n_row_tiles), 5 * n_cus // n_row_tiles, n_cols // 512 or 1))
     return n_row_tiles, splits
