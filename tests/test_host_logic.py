@@ -159,9 +159,11 @@ def test_plan_heuristics():
     from scdeepsort_amd.graph import auto_chunk, auto_tile_geometry
     assert auto_chunk(0) == 256 and auto_chunk(2_000_000) == 256 and auto_chunk(80_000_000) == 2048
     assert all(auto_chunk(n) in (256, 512, 1024, 2048) for n in (1, 3_000_000, 6_000_000, 10_000_000, 10 ** 9))
-    # cells side of cfg3: two full rounds over 256 CUs, no column split; gene side: <= five rounds, column-split
+    # cells side of cfg3: two full rounds over 256 CUs, no column split; few-row operands (the gene side, small graphs):
+    # ONE round of <= 256 workgroups, column-split, row tiles slightly shrunk to fill the round
     assert auto_tile_geometry(100_000, 20_000) == (512, 1) and auto_tile_geometry(50_000, 20_000, nnz=40_000_000) == (256, 1)
     rt, cs = auto_tile_geometry(20_600, 100_000, nnz=80_000_000)
-    assert rt * 250 >= 20_600 and cs > 1 and rt * cs <= 5 * 256
-    assert auto_tile_geometry(10_000, 10_000, nnz=4_000_000) == (40, 4)
+    assert (rt, cs) == (85, 3) and rt * 250 >= 20_600 and rt * cs <= 256
+    assert auto_tile_geometry(10_000, 10_000, nnz=4_000_000) == (42, 6)
+    assert auto_tile_geometry(300, 1_000, nnz=30_000) == (3, 1)            # a small operand is never shredded to fill CUs
     assert auto_tile_geometry(300, 100) == (2, 1)
