@@ -2,10 +2,13 @@
 """bench.py - cells embedded / s for the 2-layer WGNN forward (BASELINE.json metric) on N MI355X.
 
 A "step" = one full 2-layer forward (L1 genes<-cells, L1 cells<-genes, L2 cells<-genes, projections, head)
-over one synthetic graph already resident in HBM.  N = 1: BASELINE cfg3 (100k cells x 20k genes,
-dense_dim 400, hidden 256, 16 classes).  N > 1: weak scaling - every rank owns a cfg3-sized cell shard
-(N*100k cells in total; at N = 8 that is BASELINE cfg5's scale), gene table replicated, ONE data-path
-collective per forward (all-reduce of the [G,H] gene partial sums) + the logits all-gather.
+over one synthetic graph already resident in HBM.  The workload is BASELINE cfg3 (100k cells x 20k genes,
+dense_dim 400, hidden 256, 16 classes) at every N: with N > 1 the SAME graph (generated from the reference
+seed on every rank) is sharded along the cell axis - `"scaling": "strong"`, BASELINE cfg4's split - the gene
+table is replicated, ONE data-path collective per forward (all-reduce of the [G,H] gene partial sums) + the
+logits all-gather, and rank 0 checks the sharded logits against the unsharded evaluation of the same graph
+(`config.sharded_vs_unsharded`).  `--scaling weak` gives every rank its own cfg-sized shard instead; in a
+strong N > 1 run the weak line is measured too and printed as the secondary field `weak_scaling`.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel,
 algorithmic bytes / HIP-event launch time) and `cpu_baseline` (the CPU restatement timed on this host).
@@ -108,13 +111,76 @@ def self_launch(args):
     os.execv(sys.executable, cmd)
 
 
+def build_workload(cfg, mode, rank, world, dev, S, shard_range):
+    """This rank's operand.  ``strong``: ONE job of cfg.cells cells - every rank generates the SAME graph / features from
+    the reference seed and keeps its ``shard_range`` of the cell axis (BASELINE cfg4: "Same 100k x 20k graph ... cells
+    sharded 8-way"); also returns the whole job (for the sharded == unsharded self-check).  ``weak``: every rank owns its own
+    cfg.cells-cell shard (seed + rank)."""
+    G = cfg.genes
+    feats_g = S.synth_features(G, cfg.dense_dim, seed=7, device=dev, dtype=cfg.feature_dtype)
+    if mode == "weak":
+        rp, col, val = S.synth_expression(cfg.cells, G, cfg.density, seed=S.REFERENCE_SEED + rank, device=dev)
+        feats_c = S.synth_features(cfg.cells, cfg.dense_dim, seed=100 + rank, device=dev, dtype=cfg.feature_dtype)
+        return (rp, col, val), feats_g, feats_c, cfg.cells * world, None
+    rp, col, val = S.synth_expression(cfg.cells, G, cfg.density, seed=S.REFERENCE_SEED, device=dev)
+    feats_c = S.synth_features(cfg.cells, cfg.dense_dim, seed=100, device=dev, dtype=cfg.feature_dtype)
+    if world == 1:
+        return (rp, col, val), feats_g, feats_c, cfg.cells, None
+    lo, hi = shard_range(cfg.cells, rank, world)
+    b, e = int(rp[lo]), int(rp[hi])
+    mine = ((rp[lo:hi + 1] - rp[lo]).clone(), col[b:e].clone(), val[b:e].clone())
+    whole = (rp, col, val, feats_c) if rank == 0 else None
+    return mine, feats_g, feats_c[lo:hi].clone(), cfg.cells, whole
+
+
+def timed_steps(engine, feats_g, feats_c, steps, warmup, world, dev, profile=True):
+    """W untimed + EXACTLY K timed forwards between barrier + synchronize on both sides; returns (max-over-ranks seconds,
+    local seconds, per-launch HIP-event records, last output)."""
+    from scdeepsort_amd import ops
+
+    def step():
+        with torch.no_grad():
+            return engine.forward(feats_g, feats_c, async_gather=world > 1)    # concat of step i overlaps step i+1
+
+    out = None
+    for _ in range(warmup):
+        out = step()
+    if world > 1:
+        engine.wait_gather()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ops.PROFILE = [] if profile else None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    if world > 1:
+        engine.wait_gather()                        # the last step's concat is inside the timed region
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    prof, ops.PROFILE = ops.PROFILE, None
+    dt_local = dt
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, dt_local, prof or [], out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default=os.environ.get("WGNN_BENCH_CONFIG", "cfg3"))
+    ap.add_argument("--scaling", choices=("strong", "weak"), default=os.environ.get("WGNN_BENCH_SCALING", "strong"),
+                    help="strong (default): ONE cfg-sized job, its cells sharded over the ranks (BASELINE cfg3/cfg4/cfg5); "
+                         "weak: every rank owns a cfg-sized shard")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the weak-scaling / sustained secondary measurements")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -143,60 +209,44 @@ def main():
         pass
 
     import scdeepsort_amd as sda
-    from scdeepsort_amd import ops, synthetic as S
+    from scdeepsort_amd import synthetic as S
     from scdeepsort_amd.sharded import ShardedWgnn
 
     cfg = S.CONFIGS[args.config]
-    G, C = cfg.genes, cfg.cells                     # C = cells PER RANK (weak scaling) ...
-    if cfg.total_cells:                             # ... except cfg5: the 764,741-cell atlas is the whole job
-        lo, hi = sda.dist.shard_range(cfg.cells, rank, world)
-        C = hi - lo
+    G = cfg.genes
+    mode = args.scaling
     t_setup = time.time()
-    rp, col, val = S.synth_expression(C, G, cfg.density, seed=S.REFERENCE_SEED + rank, device=dev)
+    (rp, col, val), feats_g, feats_c, total_cells, whole = build_workload(cfg, mode, rank, world, dev, S, sda.dist.shard_range)
+    C = feats_c.shape[0]                             # cells held by THIS rank
     torch.manual_seed(1234)
     model = sda.GNN(cfg.dense_dim, cfg.hidden, cfg.n_classes, cfg.n_layers, G, activation=F.relu)
     with torch.no_grad():
         model.alpha.uniform_(0.5, 1.5)               # reference init is ones; exercise the alpha path
     model = model.to(dev).eval()
-    feats_g = S.synth_features(G, cfg.dense_dim, seed=7, device=dev, dtype=cfg.feature_dtype)
-    feats_c = S.synth_features(C, cfg.dense_dim, seed=100 + rank, device=dev, dtype=cfg.feature_dtype)
     engine = ShardedWgnn.build(model, rp, col, val, G)          # world == 1 -> plain single-GPU graph
     del rp, col, val
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
-    def step():
-        with torch.no_grad():
-            return engine.forward(feats_g, feats_c, async_gather=world > 1)    # concat of step i overlaps step i+1
-
-    for _ in range(args.warmup):
-        out = step()
-    if world > 1:
-        engine.wait_gather()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    ops.PROFILE = []
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    if world > 1:
-        engine.wait_gather()                        # the last step's concat is inside the timed region
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    dt_local = dt
-    prof, ops.PROFILE = ops.PROFILE, None
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt, dt_local, prof, out = timed_steps(engine, feats_g, feats_c, args.steps, args.warmup, world, dev)
     assert torch.isfinite(out).all()
     ms_per_step = dt / args.steps * 1e3
-    total_cells = cfg.cells if cfg.total_cells else C * world
     value = total_cells / (dt / args.steps)
+
+    # ---- N > 1, strong: the sharded job's logits against the SAME graph evaluated unsharded on rank 0's GPU (outside the
+    # timed region).  Skipped for jobs too large to repeat on one GPU within the run's time budget.
+    self_check = None
+    if world > 1 and mode == "strong" and whole is not None and total_cells <= 200_000:
+        w_rp, w_col, w_val, w_fc = whole
+        from scdeepsort_amd.graph import CellGeneGraph
+        g1 = CellGeneGraph.from_device_csr(w_rp, w_col, w_val, G)
+        with torch.no_grad():
+            ref = model.linear(model.embed(g1, (feats_g, w_fc)))
+        self_check = {"max_abs_sharded_minus_unsharded": float((out.float() - ref.float()).abs().max()),
+                      "rows_compared": int(ref.shape[0]), "tolerance": 1e-4}
+        assert self_check["max_abs_sharded_minus_unsharded"] < 1e-4, self_check
+        del g1, ref
+    whole = None
 
     # ---- roofline of the dominant kernel (HIP events on the launch stream, averaged over the timed steps)
     per = {}
@@ -236,13 +286,17 @@ def main():
     ce1.record(); torch.cuda.synchronize()
     copy_gbs = 5 * 2 * src_buf.numel() * 4 / (ce0.elapsed_time(ce1) * 1e-3) / 1e9
     del src_buf, dst_buf
+    fwd_bytes = engine.forward_alg_bytes(cfg.dense_dim, feats_g.element_size())
+    agg_ms = sum(p["avg_ms"] * p["launches_per_step"] for p in passes)
     roofline = {"bound": "hbm", "kernel": f"{dom['kernel']} (rows={dom['rows']}, src={dom['src_rows']}, D={dom['D']})",
                 "achieved": dom["achieved_GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                "traffic_note": "FETCH_SIZE counts Infinity-Cache hits (MI355X_MICROARCH.md): the excess over the algorithmic "
+                                "bytes is the per-XCD re-fetch of the source table, part of which never reaches HBM",
                 "measured_copy_GBs": round(copy_gbs, 1), "frac_of_measured_copy": round(dom["achieved_GBs"] / copy_gbs, 4),
                 "alg_bytes_per_launch": dom["alg_bytes"], "avg_launch_ms": dom["avg_ms"], "passes": passes,
-                "forward_alg_bytes": engine.forward_alg_bytes(cfg.dense_dim, feats_g.element_size()),
-                "forward_achieved_GBs": round(engine.forward_alg_bytes(cfg.dense_dim, feats_g.element_size()) / ms_per_step / 1e6, 1),
+                "agg_kernels_ms_per_step": round(agg_ms, 4), "outside_agg_kernels_ms_per_step": round(dt_local / args.steps * 1e3 - agg_ms, 4),
+                "forward_alg_bytes": fwd_bytes, "forward_achieved_GBs": round(fwd_bytes / (dt_local / args.steps * 1e3) / 1e6, 1),
                 # the resource that actually bounds the tile kernel: per launch every non-zero reads one D*4-byte source row
                 # from LDS and every tile streams its source range into LDS once
                 "on_chip": {"lds_read_bytes": dom["nnz"] * dom["D"] * 4,
@@ -258,7 +312,9 @@ def main():
         mine = {"rank": rank, "device": f"cuda:{local_rank}", "gpu": torch.cuda.get_device_name(dev), "cells": C,
                 "nnz": engine.nnz, "kernel": dom["kernel"], "avg_launch_ms": dom["avg_ms"],
                 "achieved_GBs": dom["achieved_GBs"], "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4),
-                "forward_achieved_GBs": roofline["forward_achieved_GBs"], "local_ms_per_step": round(dt_local / args.steps * 1e3, 4),
+                "forward_alg_bytes": fwd_bytes, "forward_achieved_GBs": roofline["forward_achieved_GBs"],
+                "forward_frac": round(roofline["forward_achieved_GBs"] / HBM_PEAK_GBS, 4),
+                "local_ms_per_step": round(dt_local / args.steps * 1e3, 4),
                 "passes": [{k: p[k] for k in ("kernel", "rows", "src_rows", "D", "launches_per_step", "avg_ms", "achieved_GBs")}
                            for p in passes]}
         per_gpu = [None] * world
@@ -267,6 +323,27 @@ def main():
                 "collectives_per_step": "1 all-reduce [G,H] (genes<-cells partial sums) + 1 all-gather of the logits"}
         roofline["per_gpu"] = per_gpu
         roofline["aggregate_peak_GBs"] = HBM_PEAK_GBS * (1 if share else world)
+        roofline["job_forward_achieved_GBs"] = round(sum(p["forward_alg_bytes"] for p in per_gpu) / ms_per_step / 1e6, 1)
+        roofline["job_forward_frac"] = round(roofline["job_forward_achieved_GBs"] / roofline["aggregate_peak_GBs"], 4)
+
+    # ---- secondary measurements (never `value`): a sustained run of the same step (>= ~1 s of GPU time, so that an
+    # outside sampler sees the device busy and the average is not 20 steps thin), and - N > 1 - the weak-scaling line
+    sustained, weak = None, None
+    if not args.no_secondary:
+        n_sus = max(args.steps, min(2000, int(1.2 / max(dt / args.steps, 1e-5))))
+        dt_s, _, _, _ = timed_steps(engine, feats_g, feats_c, n_sus, 0, world, dev, profile=False)
+        sustained = {"steps": n_sus, "ms_per_step": round(dt_s / n_sus * 1e3, 4), "value": round(total_cells / (dt_s / n_sus), 1),
+                     "unit": "cells/s"}
+        if world > 1 and mode == "strong" and not cfg.total_cells:
+            del engine
+            (rp, col, val), wf_g, wf_c, w_total, _ = build_workload(cfg, "weak", rank, world, dev, S, sda.dist.shard_range)
+            w_engine = ShardedWgnn.build(model, rp, col, val, G)
+            del rp, col, val
+            dt_w, _, _, _ = timed_steps(w_engine, wf_g, wf_c, args.steps, args.warmup, world, dev, profile=False)
+            weak = {"scaling": "weak", "cells_total": w_total, "cells_per_gpu": cfg.cells, "steps": args.steps,
+                    "ms_per_step": round(dt_w / args.steps * 1e3, 4), "value": round(w_total / (dt_w / args.steps), 1),
+                    "unit": "cells/s"}
+            engine = w_engine
 
     # ---- CPU baseline: the restatement (C/OpenMP aggregation + torch Linear) on this host, rank 0, N = 1 only
     cpu = None
@@ -276,14 +353,17 @@ def main():
     if rank == 0:
         line = {"metric": "cells embedded/sec (2-layer WGNN fwd)", "value": round(value, 1), "unit": "cells/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
-                "higher_is_better": True, "scaling": "strong" if cfg.total_cells else "weak", "vs_baseline": None,
+                "higher_is_better": True, "scaling": mode, "vs_baseline": None,
                 "dtype": "f32" if cfg.feature_dtype == torch.float32 else "f32 (fp16-stored input features)", "data": "synthetic",
-                "config": {"workload": f"{cfg.name}: {C} cells/GPU x {G} genes, density {cfg.density}, "
-                                       f"dense_dim {cfg.dense_dim}, hidden {cfg.hidden}, {cfg.n_layers}-layer WGNN forward "
-                                       f"+ {cfg.n_classes}-class head", "cells_total": total_cells,
-                           "nnz_per_gpu": engine.nnz, "parallelism": f"cell-shard x{world}",
-                           "setup_s": round(t_setup, 1), "communicator": comm},
-                "roofline": roofline, "cpu_baseline": cpu}
+                "config": {"workload": f"{cfg.name}: {total_cells} cells x {G} genes"
+                                       f"{' (ONE job, cells sharded over the ranks)' if mode == 'strong' else ' in total (' + str(cfg.cells) + ' per GPU)'}, "
+                                       f"density {cfg.density}, dense_dim {cfg.dense_dim}, hidden {cfg.hidden}, "
+                                       f"{cfg.n_layers}-layer WGNN forward + {cfg.n_classes}-class head",
+                           "cells_total": total_cells, "cells_this_rank": C,
+                           "nnz_per_gpu": per_gpu[0]["nnz"] if per_gpu else roofline["passes"][0]["nnz"],
+                           "parallelism": f"cell-shard x{world}", "setup_s": round(t_setup, 1), "communicator": comm,
+                           "sharded_vs_unsharded": self_check},
+                "roofline": roofline, "cpu_baseline": cpu, "sustained": sustained, "weak_scaling": weak}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -42,7 +42,11 @@
 extern "C" {
 #endif
 
-#define WGNN_VERSION 101           /* 0.1.1: neigh_sum output of the forward operators, K5, dense entries */
+#define WGNN_VERSION 200           /* 0.2.0 - INCOMPATIBLE with 0.1.x binders: `neigh_sum` was inserted before `n_out` in
+                                      wgnn_agg_fwd / wgnn_agg_fwd_tiled (0.1.1, should have been a major bump then - a 0.1.0
+                                      caller would pass n_out in a pointer slot); 0.2.0 adds int64 row pointers
+                                      (WGNN_FLAG_ROWPTR_I64, wgnn_normalize_rows_i64), WGNN_FLAG_SRC_PRESCALED and
+                                      wgnn_linear_fwd_ex.  Binders must check wgnn_version() / 100 == 2. */
 
 /* error codes */
 #define WGNN_OK                 0
@@ -69,6 +73,12 @@ extern "C" {
 #define WGNN_FLAG_NO_SELF  4u   /* skip the self-loop term                                                */
 #define WGNN_FLAG_SELF_COMPACT 8u /* h_self holds one row per OUTPUT SLOT (h_self[i]) instead of per CSR row (h_self[r]);
                                      used with row_ids for seed mini-batches (train.py:71-81)                */
+#define WGNN_FLAG_ROWPTR_I64 16u  /* `rowptr` points to int64_t[R+1] (scipy / torch CSR of large matrices) instead of int32_t[R+1].
+                                     SURVEY 8b: "rowptr[R+1] i32 or i64".  The kernels read rowptr only for the inv_deg == NULL
+                                     fallback (row length); non-zero OFFSETS stay 32-bit (plan items), so an operand still has
+                                     < 2^31 non-zeros per GPU (see wgnn_plan_build_host_i64)                    */
+#define WGNN_FLAG_SRC_PRESCALED 32u /* wgnn_agg_fwd_tiled, WGNN_SRC_IS_GENE: h_src already holds alpha[s]*h[s] (written by
+                                     wgnn_linear_fwd_ex's scaled output); no scale pass, src_scratch may be NULL */
 
 int         wgnn_version(void);
 const char* wgnn_last_error_string(int code);
@@ -123,7 +133,7 @@ int wgnn_plan_build_host_i64(const int64_t* rowptr_host, const int32_t* row_ids_
  *   gradient of alpha[r] is then inv_deg[r]*<g[r], neigh_sum[r]> - a row dot product instead of a second pass over the
  *   edges (K3).
  * ------------------------------------------------------------------------- */
-int wgnn_agg_fwd(const int32_t* rowptr, const int32_t* col, const float* val,
+int wgnn_agg_fwd(const void* rowptr /* int32_t[R+1]; int64_t[R+1] with WGNN_FLAG_ROWPTR_I64 */, const int32_t* col, const float* val,
                  const float* alpha, int alpha_mode, int32_t self_idx,
                  const void* h_src, int64_t ld_src,
                  const void* h_self, int64_t ld_self,
@@ -152,7 +162,7 @@ int wgnn_agg_fwd(const int32_t* rowptr, const int32_t* col, const float* val,
  *   src_scratch: float[n_src * D], required for WGNN_SRC_IS_GENE: alpha is folded into the source rows
  *                once ((h*alpha), gnn.py:54) instead of once per edge.
  * ------------------------------------------------------------------------- */
-int wgnn_agg_fwd_tiled(const int32_t* rowptr, const float* alpha, int alpha_mode, int32_t self_idx,
+int wgnn_agg_fwd_tiled(const void* rowptr /* int32_t[R+1] | int64_t[R+1] (WGNN_FLAG_ROWPTR_I64) | NULL with inv_deg */, const float* alpha, int alpha_mode, int32_t self_idx,
                        const float* h_src, int64_t n_src, float* src_scratch,
                        const float* h_self, int64_t ld_self,
                        const int32_t* row_ids, const float* inv_deg, const float* bias,
@@ -233,6 +243,9 @@ int wgnn_agg_bwd_alpha_tiled(const float* inv_deg, const float* g, int64_t ld_g,
  * ------------------------------------------------------------------------- */
 int wgnn_normalize_rows(const int32_t* rowptr, const float* val_in, float* val_out, float* inv_deg,
                         int64_t n_rows, void* stream);
+/* the same over a 64-bit row-pointer array ("rowptr[R+1] i32 or i64") */
+int wgnn_normalize_rows_i64(const int64_t* rowptr, const float* val_in, float* val_out, float* inv_deg,
+                            int64_t n_rows, void* stream);
 
 /* ---------------------------------------------------------------------------
  * K5  seeded neighbour subsampling (train.py:37-40,71-78: NeighborSampler(expand_factor = num_neighbors,
@@ -258,6 +271,15 @@ int wgnn_sample_rows(const int32_t* rowptr, const int32_t* col, const float* val
  * classifier head `linear(h)` (models/gnn.py:66-67).  flags: WGNN_FLAG_RELU or 0.  K, ld_x, ld_w multiples of 4,
  * x / w 16-byte aligned; M, N arbitrary.  bias may be NULL.  Makes the ABI self-sufficient for one whole layer.
  * ------------------------------------------------------------------------- */
+/* Extended form (0.2.0):
+ *   x_dtype WGNN_F32 | WGNN_F16: fp16-STORED features (BASELINE cfg5) are widened in registers on their way into LDS - fp16-
+ *     rounded inputs, fp32 multiply-accumulate, no fp32 copy of x in HBM (x 8-byte aligned then);
+ *   row_scale / out_scaled (both or neither): out_scaled[m, :] = row_scale[m] * out[m, :], written from the same
+ *     accumulators.  With row_scale = alpha[0:G] this is the alpha-folded gene table (h*alpha, models/gnn.py:54) that
+ *     wgnn_agg_fwd_tiled takes under WGNN_FLAG_SRC_PRESCALED - no separate scale pass.  `out` may be NULL then. */
+int wgnn_linear_fwd_ex(const void* x, int x_dtype, int64_t ld_x, const float* w, int64_t ld_w, const float* bias,
+                       float* out, int64_t ld_out, const float* row_scale, float* out_scaled, int64_t ld_out_scaled,
+                       int64_t M, int32_t N, int32_t K, uint32_t flags, void* stream);
 int wgnn_linear_fwd(const float* x, int64_t ld_x, const float* w, int64_t ld_w, const float* bias,
                     float* out, int64_t ld_out, int64_t M, int32_t N, int32_t K, uint32_t flags, void* stream);
 
@@ -278,7 +300,7 @@ int wgnn_linear_wgrad(const float* g, int64_t ld_g, const float* x, int64_t ld_x
  * neigh_scratch: float[n_out * D] (caller-owned); W: float[H, ld_w] (nn.Linear layout), bias: float[H] or NULL;
  * lin_flags: WGNN_FLAG_RELU or 0; out: float[n_out, ld_out].
  * ------------------------------------------------------------------------- */
-int wgnn_agg_linear_relu_fwd(const int32_t* rowptr, const int32_t* col, const float* val,
+int wgnn_agg_linear_relu_fwd(const void* rowptr /* as wgnn_agg_fwd */, const int32_t* col, const float* val,
                              const float* alpha, int alpha_mode, int32_t self_idx,
                              const float* h_src, int64_t ld_src, const float* h_self, int64_t ld_self,
                              const int32_t* row_ids, const float* inv_deg,

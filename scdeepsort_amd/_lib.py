@@ -14,7 +14,8 @@ LIB_PATH = Path(__file__).resolve().parent / "libwgnn_hip.so"
 # error codes / enums (mirror include/wgnn.h)
 SRC_IS_GENE, DST_IS_GENE, NO_ALPHA = 0, 1, 2
 F32, F16 = 0, 1
-FLAG_RELU, FLAG_NO_MEAN, FLAG_NO_SELF, FLAG_SELF_COMPACT = 1, 2, 4, 8
+FLAG_RELU, FLAG_NO_MEAN, FLAG_NO_SELF, FLAG_SELF_COMPACT, FLAG_ROWPTR_I64, FLAG_SRC_PRESCALED = 1, 2, 4, 8, 16, 32
+ABI_MAJOR = 2                      # include/wgnn.h WGNN_VERSION / 100
 
 _vp, _i32, _i64, _u32, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_int
 
@@ -40,8 +41,10 @@ SIGNATURES = {
     "wgnn_agg_bwd_alpha": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp,
                                      _i64, _i32, _u32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
     "wgnn_normalize_rows": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
+    "wgnn_normalize_rows_i64": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp]),
     "wgnn_sample_rows": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, C.c_uint64, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "wgnn_linear_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _u32, _vp]),
+    "wgnn_linear_fwd_ex": (C.c_int, [_vp, _int, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _u32, _vp]),
     "wgnn_linear_wgrad_workspace": (C.c_int, [_i64, _i32, _i32, _vp, _vp]),
     "wgnn_linear_wgrad": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _int, _vp, _i64, _vp]),
     "wgnn_agg_linear_relu_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _int, _i32, _vp, _i64, _vp, _i64, _vp, _vp,
@@ -64,6 +67,8 @@ def lib() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(dll, name)          # AttributeError here = header/ABI drift
         fn.restype, fn.argtypes = res, args
+    if dll.wgnn_version() // 100 != ABI_MAJOR:
+        raise WgnnError(f"{LIB_PATH} speaks ABI {dll.wgnn_version()}, this binding needs major version {ABI_MAJOR}: rebuild it")
     return dll
 
 

@@ -27,9 +27,9 @@ from .graph import CellGeneGraph
 def _device(gpu_id: int) -> torch.device:
     if not torch.cuda.is_available():
         raise WgnnError("the MI355X path needs a GPU (gpu_id=-1 meant CPU in the reference; there is no CPU fallback here)")
-    dev = torch.device("cuda", max(gpu_id, 0))
-    torch.cuda.set_device(dev)                                # the C ABI launches on the current device's streams
-    return dev
+    # the caller's current device is left alone: every C-ABI call runs under ``_lib.call``'s device guard and every tensor
+    # below is created on ``dev`` explicitly
+    return torch.device("cuda", max(gpu_id, 0))
 
 
 def _read_expression(path, file_type: str) -> pd.DataFrame:
@@ -183,18 +183,27 @@ class DeepSortClassifier:
         val_ids = torch.from_numpy(perm[:n_val] + G).to(dev); train_ids = torch.from_numpy(perm[n_val:] + G).to(dev)
         model = GNN(self.dense_dim, self.hidden_dim, len(id2label), self.n_layers, G, activation=F.relu,
                     dropout=self.dropout).to(dev)
-        opt = torch.optim.Adam(model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay,    # train.py:34-35
-                               capturable=True)        # step counter on the device: no host sync, hipGraph-capturable
         best, self.history = -1.0, []
         sample_gen = None
         if self.num_neighbors:                                               # train.py:39-40,71-78
             from .sampler import DeviceSampler
             seed = self.random_seed if self.random_seed is not None else torch.initial_seed() % 2 ** 31
-            if min(self.num_neighbors, max(graph.cg.max_row_nnz, graph.gc.max_row_nnz) + 1) <= 256:
+            kk = min(self.num_neighbors, max(graph.cg.max_row_nnz, graph.gc.max_row_nnz) + 1)
+            # K5's static NodeFlow draws for ALL cells and genes below the last block (O((C+G) k) per layer, capturable);
+            # the closure sampler only touches the nodes a batch reaches (~ B k^(L-1)) but has data-dependent shapes.
+            # Static pays off when the closure is a sizeable part of the graph anyway, and always for one layer.
+            closure = self.batch_size * kk ** max(0, self.n_layers - 1)
+            if kk <= 256 and (self.n_layers == 1 or 4 * closure >= C + G):
                 sample_gen = DeviceSampler(seed, dev)                        # K5: static shapes, sync-free, capturable
-            else:                                                            # very wide draws: torch-op sampler
+            else:                                                            # very wide draws / shallow closures: torch-op sampler
                 sample_gen = torch.Generator(device=dev)
                 sample_gen.manual_seed(seed)
+        # static shapes (full neighbourhoods, or NodeFlows drawn by the device sampler): one hipGraph launch per batch
+        static_shapes = not self.num_neighbors or not isinstance(sample_gen, torch.Generator)
+        will_graph = self.graph_steps and static_shapes and len(train_ids) >= 8 * self.batch_size
+        # train.py:34-35.  `capturable` (step counter and bias correction on device tensors) only when a step is actually
+        # replayed as a hipGraph; otherwise the reference's plain Adam arithmetic
+        opt = torch.optim.Adam(model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay, capturable=will_graph)
         save_path = Path(save_path) if save_path is not None else None
         if save_path is not None:
             save_path.mkdir(parents=True, exist_ok=True)
@@ -218,9 +227,7 @@ class DeepSortClassifier:
             return loss.detach()
 
         step = train_step
-        static_shapes = not self.num_neighbors or not isinstance(sample_gen, torch.Generator)
-        if self.graph_steps and static_shapes and len(train_ids) >= 8 * self.batch_size:
-            # static shapes (full neighbourhoods, or NodeFlows drawn by the device sampler): one hipGraph launch per batch
+        if will_graph:
             from .graphed import GraphedTrainStep
             step = GraphedTrainStep(train_step, self.batch_size, dev)
         self._step = step

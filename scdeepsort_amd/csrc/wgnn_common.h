@@ -14,7 +14,8 @@ constexpr int kBlock = 64 * kWavesPerBlock;
 enum { EPI_FWD = 0, EPI_BWD_SRC = 1, EPI_BWD_ALPHA = 2 };
 
 struct KArgs {
-    const int* rowptr; const int* col; const float* val;
+    const void* rowptr;                          // int32[R+1], or int64[R+1] when flags & WGNN_FLAG_ROWPTR_I64
+    const int* col; const float* val;
     const float* cs1; const float* cs2;          // optional per-column scale factors (alpha[col], inv_deg[col])
     const void* src; long ld_src;                // gathered rows
     const float* alpha; int mode; int self_idx;
@@ -59,13 +60,23 @@ __device__ __forceinline__ float group_sum(float v) {
     return v;
 }
 
+// in-degree of CSR row r from the caller's row-pointer array (32- or 64-bit entries)
+__device__ __forceinline__ float row_degree(const KArgs& a, long r) {
+    if (a.flags & WGNN_FLAG_ROWPTR_I64) {
+        const long long* p = reinterpret_cast<const long long*>(a.rowptr);
+        return (float)(p[r + 1] - p[r]);
+    }
+    const int* p = reinterpret_cast<const int*>(a.rowptr);
+    return (float)(p[r + 1] - p[r]);
+}
+
 // Shared epilogue: turns the accumulated neighbour sum of one row into the kernel's outputs.
 template <int LPR, int NV, typename TIn, typename TOut, int EPI>
 __device__ __forceinline__ void epilogue(const KArgs& a, float4 (&acc)[NV], int slot, int l, bool writer) {
     const int r = a.row_ids ? a.row_ids[slot] : slot;
     float invd = 1.0f;
     if (!(a.flags & WGNN_FLAG_NO_MEAN)) {
-        invd = a.inv_deg ? a.inv_deg[r] : 1.0f / (float)(a.rowptr[r + 1] - a.rowptr[r] + 1);
+        invd = a.inv_deg ? a.inv_deg[r] : 1.0f / (row_degree(a, r) + 1.0f);
     }
     if constexpr (EPI == EPI_FWD) {
         const float rs = invd * (a.mode == WGNN_DST_IS_GENE ? a.alpha[r] : 1.0f);

@@ -142,17 +142,18 @@ __global__ void __launch_bounds__(kBlock) agg_finalize(const KArgs a) {
 }
 
 // K4: normalize_weight - one wave per row
-__global__ void __launch_bounds__(kBlock) normalize_rows(const int* __restrict__ rowptr, const float* __restrict__ vin,
+template <typename TPtr>
+__global__ void __launch_bounds__(kBlock) normalize_rows(const TPtr* __restrict__ rowptr, const float* __restrict__ vin,
                                                          float* __restrict__ vout, float* __restrict__ inv_deg, long n_rows) {
     const int lane = threadIdx.x & 63;
     const long r = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (r >= n_rows) return;
-    const int b = rowptr[r], e = rowptr[r + 1];
+    const TPtr b = rowptr[r], e = rowptr[r + 1];
     float s = 0.f;
-    for (int j = b + lane; j < e; j += 64) s += vin[j];
+    for (TPtr j = b + lane; j < e; j += 64) s += vin[j];
     s = group_sum<64>(s);
     const float deg = (float)(e - b);
-    for (int j = b + lane; j < e; j += 64) vout[j] = deg * vin[j] / s;     // (deg*w)/sum, preprocess_internal.py:23
+    for (TPtr j = b + lane; j < e; j += 64) vout[j] = deg * vin[j] / s;    // (deg*w)/sum, preprocess_internal.py:23
     if (inv_deg && lane == 0) inv_deg[r] = 1.0f / (deg + 1.0f);
 }
 
@@ -231,6 +232,16 @@ static int plan_build(const TPtr* rowptr, const int32_t* row_ids, int64_t n_rows
     return WGNN_OK;
 }
 
+template <typename TPtr>
+static int normalize_rows_launch(const TPtr* rowptr, const float* val_in, float* val_out, float* inv_deg, int64_t n_rows, void* stream) {
+    if (!rowptr || !val_in || !val_out || n_rows < 0) return WGNN_ERR_BAD_ARG;
+    if (n_rows == 0) return WGNN_OK;
+    const long nb = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
+    hipLaunchKernelGGL(normalize_rows<TPtr>, dim3((unsigned)nb), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       rowptr, val_in, val_out, inv_deg, (long)n_rows);
+    return hipGetLastError() == hipSuccess ? WGNN_OK : WGNN_ERR_LAUNCH;
+}
+
 extern "C" {
 
 int wgnn_version(void) { return WGNN_VERSION; }
@@ -278,7 +289,7 @@ static int check_common(int32_t D, int64_t n, const void* items, int64_t n_items
     return WGNN_OK;
 }
 
-int wgnn_agg_fwd(const int32_t* rowptr, const int32_t* col, const float* val,
+int wgnn_agg_fwd(const void* rowptr, const int32_t* col, const float* val,
                  const float* alpha, int alpha_mode, int32_t self_idx,
                  const void* h_src, int64_t ld_src, const void* h_self, int64_t ld_self,
                  const int32_t* row_ids, const float* inv_deg, const float* bias,
@@ -365,12 +376,12 @@ int wgnn_agg_bwd_alpha(const int32_t* rowptr, const int32_t* col, const float* v
 
 int wgnn_normalize_rows(const int32_t* rowptr, const float* val_in, float* val_out, float* inv_deg,
                         int64_t n_rows, void* stream) {
-    if (!rowptr || !val_in || !val_out || n_rows < 0) return WGNN_ERR_BAD_ARG;
-    if (n_rows == 0) return WGNN_OK;
-    const long nb = (n_rows + kWavesPerBlock - 1) / kWavesPerBlock;
-    hipLaunchKernelGGL(normalize_rows, dim3((unsigned)nb), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
-                       rowptr, val_in, val_out, inv_deg, (long)n_rows);
-    return hipGetLastError() == hipSuccess ? WGNN_OK : WGNN_ERR_LAUNCH;
+    return normalize_rows_launch<int>(rowptr, val_in, val_out, inv_deg, n_rows, stream);
+}
+
+int wgnn_normalize_rows_i64(const int64_t* rowptr, const float* val_in, float* val_out, float* inv_deg,
+                            int64_t n_rows, void* stream) {
+    return normalize_rows_launch<long long>(reinterpret_cast<const long long*>(rowptr), val_in, val_out, inv_deg, n_rows, stream);
 }
 
 }  // extern "C"

@@ -29,13 +29,21 @@ constexpr int kBM = 128, kBN = 128, kBK = WGNN_LIN_BK, kLd = kBK + 1;
 constexpr int kLinThreads = 256;
 
 struct LinArgs {
-    const float* x; long ld_x;
+    const void* x; long ld_x;            // f32 or f16 rows (TX); f16 is widened in registers on the way into LDS
     const float* w; long ld_w;
     const float* bias;
-    float* out; long ld_out;
+    float* out; long ld_out;             // may be null when only the scaled copy is wanted
+    const float* row_scale;              // optional [M]: out2[m, :] = row_scale[m] * act(x W^T + bias)[m, :]
+    float* out2; long ld_out2;
     long M; int N; int K; unsigned flags;
 };
 
+// TX = float | __half: storage type of X.  fp16-stored node features (BASELINE cfg5) are read as 8-byte groups of four
+// halves and converted in registers (fp16-rounded inputs, fp32 multiply-accumulate) - no fp32 copy of [C, 400] in HBM.
+// out2: a second, row-scaled copy of the result written from the same accumulators - the projected gene table P_g and
+// its alpha-folded form alpha[g] * P_g[g] (the source table of the LDS-streamed cells<-genes pass, models/gnn.py:54's
+// (h * alpha) factor) come out of ONE kernel instead of GEMM + scale_rows.
+template <typename TX>
 __global__ void __launch_bounds__(kLinThreads) linear_mfma_f32(const LinArgs a) {
     __shared__ float As[2][kBM * kLd];
     __shared__ float Ws[2][kBN * kLd];
@@ -65,7 +73,7 @@ __global__ void __launch_bounds__(kLinThreads) linear_mfma_f32(const LinArgs a) 
             const long row = m0 + lr + kRPP * i;
             const int col = n0 + lr + kRPP * i;
             const bool kin = k0 + lk < a.K;                    // K % 4 == 0: a float4 is inside or outside as a whole
-            xa[i] = (row < a.M && kin) ? ld4(a.x + row * a.ld_x + k0 + lk) : make_float4(0.f, 0.f, 0.f, 0.f);
+            xa[i] = (row < a.M && kin) ? ld4(reinterpret_cast<const TX*>(a.x) + row * a.ld_x + k0 + lk) : make_float4(0.f, 0.f, 0.f, 0.f);
             wa[i] = (col < a.N && kin) ? ld4(a.w + (long)col * a.ld_w + k0 + lk) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
@@ -117,7 +125,8 @@ __global__ void __launch_bounds__(kLinThreads) linear_mfma_f32(const LinArgs a) 
                 if (row < a.M) {
                     float v = acc[i][j][r] + bv;
                     if (relu) v = fmaxf(v, 0.f);
-                    a.out[row * a.ld_out + col] = v;
+                    if (a.out) a.out[row * a.ld_out + col] = v;
+                    if (a.out2) a.out2[row * a.ld_out2 + col] = a.row_scale[row] * v;
                 }
             }
         }
@@ -255,24 +264,36 @@ extern "C" int wgnn_linear_wgrad(const float* g, int64_t ld_g, const float* x, i
     return hipGetLastError() == hipSuccess ? WGNN_OK : WGNN_ERR_LAUNCH;
 }
 
-extern "C" int wgnn_linear_fwd(const float* x, int64_t ld_x, const float* w, int64_t ld_w, const float* bias,
-                               float* out, int64_t ld_out, int64_t M, int32_t N, int32_t K, uint32_t flags, void* stream) {
-    if (!x || !w || !out || M < 0 || N <= 0 || K <= 0) return WGNN_ERR_BAD_ARG;
+extern "C" int wgnn_linear_fwd_ex(const void* x, int x_dtype, int64_t ld_x, const float* w, int64_t ld_w, const float* bias,
+                                  float* out, int64_t ld_out, const float* row_scale, float* out_scaled, int64_t ld_out_scaled,
+                                  int64_t M, int32_t N, int32_t K, uint32_t flags, void* stream) {
+    if (!x || !w || (!out && !out_scaled) || M < 0 || N <= 0 || K <= 0) return WGNN_ERR_BAD_ARG;
     if (flags & ~WGNN_FLAG_RELU) return WGNN_ERR_BAD_ARG;
-    if (K % 4 || ld_x % 4 || ld_w % 4 || !aligned16(x) || !aligned16(w)) return WGNN_ERR_ALIGNMENT;
-    if (ld_x < K || ld_w < K || ld_out < N) return WGNN_ERR_BAD_ARG;
+    if (x_dtype != WGNN_F32 && x_dtype != WGNN_F16) return WGNN_ERR_BAD_ARG;
+    if ((out_scaled != nullptr) != (row_scale != nullptr)) return WGNN_ERR_BAD_ARG;
+    if (K % 4 || ld_x % 4 || ld_w % 4 || !aligned16(w)) return WGNN_ERR_ALIGNMENT;
+    if (x_dtype == WGNN_F32 ? !aligned16(x) : !aligned8(x)) return WGNN_ERR_ALIGNMENT;
+    if (ld_x < K || ld_w < K || (out && ld_out < N) || (out_scaled && ld_out_scaled < N)) return WGNN_ERR_BAD_ARG;
     if (M == 0) return WGNN_OK;
     const long tiles = ((M + kBM - 1) / kBM) * ((N + kBN - 1) / kBN);
     if (tiles > 0x7FFFFFFFL) return WGNN_ERR_UNSUPPORTED;
-    LinArgs a{x, (long)ld_x, w, (long)ld_w, bias, out, (long)ld_out, (long)M, N, K, flags};
-    hipLaunchKernelGGL(linear_mfma_f32, dim3((unsigned)tiles), dim3(kLinThreads), 0, static_cast<hipStream_t>(stream), a);
+    LinArgs a{x, (long)ld_x, w, (long)ld_w, bias, out, (long)ld_out, row_scale, out_scaled, (long)ld_out_scaled, (long)M, N, K, flags};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (x_dtype == WGNN_F16) hipLaunchKernelGGL(linear_mfma_f32<__half>, dim3((unsigned)tiles), dim3(kLinThreads), 0, st, a);
+    else hipLaunchKernelGGL(linear_mfma_f32<float>, dim3((unsigned)tiles), dim3(kLinThreads), 0, st, a);
     return hipGetLastError() == hipSuccess ? WGNN_OK : WGNN_ERR_LAUNCH;
+}
+
+extern "C" int wgnn_linear_fwd(const float* x, int64_t ld_x, const float* w, int64_t ld_w, const float* bias,
+                               float* out, int64_t ld_out, int64_t M, int32_t N, int32_t K, uint32_t flags, void* stream) {
+    if (!out) return WGNN_ERR_BAD_ARG;
+    return wgnn_linear_fwd_ex(x, WGNN_F32, ld_x, w, ld_w, bias, out, ld_out, nullptr, nullptr, 0, M, N, K, flags, stream);
 }
 
 // One whole reference layer on a block, in the reference's literal order (aggregate, then NodeUpdate):
 //     neigh = block_compute(message_func, fn.mean)        (gnn.py:47-56,65)    -> K1 into `neigh_scratch`
 //     out   = relu(fc_neigh(neigh))                        (gnn.py:18-25)       -> wgnn_linear_fwd
-extern "C" int wgnn_agg_linear_relu_fwd(const int32_t* rowptr, const int32_t* col, const float* val,
+extern "C" int wgnn_agg_linear_relu_fwd(const void* rowptr, const int32_t* col, const float* val,
                                         const float* alpha, int alpha_mode, int32_t self_idx,
                                         const float* h_src, int64_t ld_src, const float* h_self, int64_t ld_self,
                                         const int32_t* row_ids, const float* inv_deg,

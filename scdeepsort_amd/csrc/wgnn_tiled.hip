@@ -428,7 +428,7 @@ namespace wgnn {
 int launch_finalize_f32(const KArgs& a, int epi, hipStream_t st);     // defined in wgnn_kernels.hip
 }
 
-extern "C" int wgnn_agg_fwd_tiled(const int32_t* rowptr, const float* alpha, int alpha_mode, int32_t self_idx,
+extern "C" int wgnn_agg_fwd_tiled(const void* rowptr, const float* alpha, int alpha_mode, int32_t self_idx,
                                   const float* h_src, int64_t n_src, float* src_scratch,
                                   const float* h_self, int64_t ld_self,
                                   const int32_t* row_ids, const float* inv_deg, const float* bias,
@@ -448,11 +448,12 @@ extern "C" int wgnn_agg_fwd_tiled(const int32_t* rowptr, const float* alpha, int
         return WGNN_ERR_ALIGNMENT;
     if (n_tiles > 0 && (!tile_items || !tile_hdr || !entries || !seg_ptr)) return WGNN_ERR_BAD_ARG;
     if (n_long > 0 && (!long_rows || !partials || n_partials <= 0)) return WGNN_ERR_WORKSPACE;
-    if (alpha_mode == WGNN_SRC_IS_GENE && (!src_scratch || !aligned16(src_scratch))) return WGNN_ERR_WORKSPACE;
+    const bool fold_alpha = alpha_mode == WGNN_SRC_IS_GENE && !(flags & WGNN_FLAG_SRC_PRESCALED);
+    if (fold_alpha && (!src_scratch || !aligned16(src_scratch))) return WGNN_ERR_WORKSPACE;
     if (n_out == 0 || n_tiles == 0) return WGNN_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const float* src = h_src;
-    if (alpha_mode == WGNN_SRC_IS_GENE) {                         // (h*alpha) once per source row, gnn.py:54
+    if (fold_alpha) {                                             // (h*alpha) once per source row, gnn.py:54
         const long n4 = (long)n_src * (D / 4);
         hipLaunchKernelGGL(scale_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, h_src, alpha, src_scratch,
                            (long)n_src, D / 4);

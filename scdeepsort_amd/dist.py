@@ -40,8 +40,22 @@ def world() -> Tuple[int, int]:
     return 0, 1
 
 
+# A one-rank communicator normally short-circuits every collective (there is nothing to exchange).  With this switch on,
+# an INITIALISED process group of any size - also a single rank - runs them all: that is how the RCCL branch (library
+# load, ``device_id=``, stream-ordered ``work.wait()``, ``all_gather_into_tensor``) is exercised on a 1-GPU box, where
+# RCCL refuses two ranks on one device (tests/test_gpu_dist.py::test_world1_nccl_*).
+FORCE_COLLECTIVES = False
+
+
+def comm_active() -> bool:
+    """True when collectives must actually be issued."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or FORCE_COLLECTIVES
+
+
 def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
-    if world()[1] > 1:
+    if comm_active():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 
@@ -88,7 +102,7 @@ class _AllReduceSum(torch.autograd.Function):
 
 def all_reduce_sum(x: torch.Tensor) -> torch.Tensor:
     """Differentiable SUM all-reduce (out of place)."""
-    return _AllReduceSum.apply(x) if world()[1] > 1 else x
+    return _AllReduceSum.apply(x) if comm_active() else x
 
 
 @dataclass
@@ -144,7 +158,7 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
         else:
             # the ONE data-path collective (X2) runs on the communicator's stream while this rank's
             # cells<-genes pass (row-independent, no communication) computes
-            work = dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=True) if world()[1] > 1 else None
+            work = dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=True) if comm_active() else None
             new_c = ops.cells_layer(p_g, p_c, b, relu) if rows is None else ops.cells_layer(p_g, p_c, b, relu, rows, False)
             if work is not None:
                 work.wait()                             # stream-level dependency on GPU backends, no host sync
@@ -154,33 +168,28 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
     Wo, bo = weights[n_layers]
     logits = torch.nn.functional.linear(h_c, Wo, bo)
     rank, ws = world()
-    if gather_logits and ws > 1 and shard_sizes is not None and len(set(shard_sizes)) == 1:
-        out = torch.empty((ws * logits.shape[0], logits.shape[1]), dtype=logits.dtype, device=logits.device)
-        work = dist.all_gather_into_tensor(out, logits.contiguous(), async_op=async_gather)    # X3: inference concat
-        return (out, work) if async_gather else out
-    if gather_logits and ws > 1:
-        if shard_sizes is not None:
-            mx = max(shard_sizes)
-            pad = torch.zeros(mx, logits.shape[1], dtype=logits.dtype, device=logits.device)
-            pad[: logits.shape[0]] = logits
-            outs = [torch.empty_like(pad) for _ in range(ws)]
-            dist.all_gather(outs, pad)
-            cat = torch.cat([o[:n] for o, n in zip(outs, shard_sizes)])
-            return (cat, None) if async_gather else cat
-        sizes = [torch.zeros(1, dtype=torch.long, device=logits.device) for _ in range(ws)]
-        dist.all_gather(sizes, torch.tensor([logits.shape[0]], dtype=torch.long, device=logits.device))
-        mx = int(max(s.item() for s in sizes))
+    if gather_logits and comm_active():
+        if shard_sizes is None or len(shard_sizes) != ws:
+            # the sizes are known when the graph is sharded (ShardedWgnn.build exchanges them once): no per-forward size
+            # exchange, no device->host read on the data path
+            raise ValueError("gather_logits on a sharded job needs shard_sizes (cells per rank, one entry per rank)")
+        if len(set(shard_sizes)) == 1:
+            out = torch.empty((ws * logits.shape[0], logits.shape[1]), dtype=logits.dtype, device=logits.device)
+            work = dist.all_gather_into_tensor(out, logits.contiguous(), async_op=async_gather)    # X3: inference concat
+            return (out, work) if async_gather else out
+        mx = max(shard_sizes)                           # ragged shards: pad to the largest, gather, cut
         pad = torch.zeros(mx, logits.shape[1], dtype=logits.dtype, device=logits.device)
         pad[: logits.shape[0]] = logits
         outs = [torch.empty_like(pad) for _ in range(ws)]
-        dist.all_gather(outs, pad)                      # X3: inference concat
-        logits = torch.cat([o[: int(s.item())] for o, s in zip(outs, sizes)])
+        dist.all_gather(outs, pad)
+        cat = torch.cat([o[:n] for o, n in zip(outs, shard_sizes)])
+        return (cat, None) if async_gather else cat
     return (logits, None) if async_gather else logits
 
 
 def all_reduce_grads(params) -> None:
     """X1: SUM all-reduce of parameter gradients in one flat bucket (~0.8 MB at cfg3)."""
-    if world()[1] == 1:
+    if not comm_active():
         return
     grads = [p.grad for p in params if p.grad is not None]
     if not grads:

@@ -118,13 +118,17 @@ class GNN(nn.Module):
             p_g = _linear(h_g, W)
             need_all_cells = (want_genes or not compact) and not h_c_compact
             p_c_all = _linear(h_c, W) if need_all_cells else None
+            self_compact = compact
             if h_c_compact:
                 p_c_self = F.linear(h_c, W)
+            elif not compact:
+                p_c_self = p_c_all
+            elif p_c_all is not None:                    # every cell's projection exists (the next layer's genes read it):
+                p_c_self, self_compact = p_c_all, False  # the seeds' self rows are read in place, no [B, H] gather
             else:
-                p_c_self = p_c_all if not compact else (p_c_all[cell_rows.long()] if p_c_all is not None
-                                                        else F.linear(h_c[cell_rows.long()], W))
+                p_c_self = F.linear(h_c[cell_rows.long()], W)
             out_c = weighted_mean_aggregate(g.cg, self.alpha, SRC_IS_GENE, G + 1, p_g, p_c_self, bias=b,
-                                            relu=fuse_relu, row_ids=cell_rows, self_compact=compact)
+                                            relu=fuse_relu, row_ids=cell_rows, self_compact=self_compact)
             out_g = None
             if want_genes:
                 out_g = weighted_mean_aggregate(g.gc, self.alpha, DST_IS_GENE, G, p_c_all, p_g, bias=b, relu=fuse_relu)

@@ -31,6 +31,7 @@ import torch
 from . import _lib
 
 DEFAULT_CHUNK = 2048
+TRANSPOSE_CHUNK = 2048       # device-built source-major blocks: longest run of entries one wave reduces serially
 
 
 def auto_chunk(nnz: int) -> int:
@@ -167,8 +168,10 @@ class AggCsr:
             skey, perm = torch.sort(key, stable=True)
             t_rowptr32 = torch.searchsorted(skey, torch.arange(self.n_cols + 1, device=dev, dtype=torch.int32)).to(torch.int32)
             t_val = torch.where(valid[perm], self.val[perm], torch.zeros((), device=dev)).contiguous()
+            # a source is drawn by at most every row once; a hub source (up to n entries) is cut into <= 8 items of >= 2048
+            # entries whose partial sums agg_finalize folds - one wave per source would serialise the hub genes
             self._t = AggCsr(t_rowptr32, owner[perm].to(torch.int32).contiguous(), t_val, torch.empty(0, device=dev),
-                             self.n_cols, n, device_plan(t_rowptr32, self.n_cols, max(1, n), max(1, n)), None)   # one item per source
+                             self.n_cols, n, device_plan(t_rowptr32, self.n_cols, max(1, n), TRANSPOSE_CHUNK), None)
             self._t._max_row_nnz = max(1, n)
         if self._t is None:
             dev = self.device
@@ -182,7 +185,7 @@ class AggCsr:
             t_val = self.val[order].contiguous()
             t_rowptr32 = t_rowptr.to(torch.int32)
             if self.rowptr_host is None:             # device-built block: a source feeds at most every row once
-                plan, host = device_plan(t_rowptr32, self.n_cols, max(1, self.n_rows), max(1, self.n_rows)), None   # one item per source
+                plan, host = device_plan(t_rowptr32, self.n_cols, max(1, self.n_rows), TRANSPOSE_CHUNK), None   # hub sources: <= 8 items
             else:
                 host = t_rowptr32.cpu().numpy()
                 plan = build_plan(host, self.plan.chunk, device=dev)
@@ -214,8 +217,11 @@ class AggCsr:
         in a hipGraph.  Every seed row gets the same number S = ceil(longest row / chunk) of items, cut at the SAME chunk
         boundaries as the full-graph plan (later items of short rows are empty); S > 1 rows fold their partial sums in
         ``agg_finalize`` in chunk order, so a seed's result is bit-identical to its row of the full-graph pass whatever
-        batch it arrives in.  Not cached: the id tensor's contents change from batch to batch (a captured step re-runs
-        this)."""
+        batch it arrives in.  Exception: an operand whose longest row needs more than 64 chunks (> 64 x plan.chunk
+        non-zeros) cuts every seed row into 64 EQUAL parts instead - still deterministic and identical from batch to batch,
+        but summed in a different order than the full-graph pass (equal to ~1 ulp of the partial sums, not bitwise;
+        ``tests/test_gpu_parity.py::test_subplan_with_pathologically_long_rows``).  Not cached: the id tensor's contents
+        change from batch to batch (a captured step re-runs this)."""
         dev = self.device
         ids32 = row_ids.to(device=dev, dtype=torch.int32).contiguous()
         B = ids32.shape[0]
@@ -249,6 +255,11 @@ class AggCsr:
         Static shapes (cap = batch x longest row, padding sorted behind a sentinel key): no host synchronisation."""
         dev = self.device
         B = ids32.shape[0]
+        if B == 0:                                                        # no seed: every source row is empty
+            z = torch.zeros(self.n_cols + 1, dtype=torch.int32, device=dev)
+            rows = torch.arange(self.n_cols, device=dev, dtype=torch.int32)
+            return (z, torch.zeros(1, dtype=torch.int32, device=dev), torch.zeros(1, device=dev),
+                    torch.stack([rows, z[:-1], z[1:], torch.full_like(rows, -1)], 1).contiguous())
         cap = max(1, B * max(1, self.max_row_nnz))
         idl = ids32.long()
         beg = self.rowptr[idl].long()

@@ -55,6 +55,8 @@ SEED_BLOCK_MAX_CAP = 12_000_000     # B x longest row above which a seed batch's
                                     # (sorting the padded block costs ~0.05 ms per million slots; the full K2t pass 1.2 ms at cfg3)
 PAD_NARROW_TO_256 = False           # round-1 behaviour (hidden < 256 carried as 256 zero-padded columns); kept for A/B timing
 TILED_MIN_WORK = 500_000_000        # nnz*D above which the LDS-streamed kernels win (measured crossover: ~2 M edges at D = 256)
+SEED_FULL_PASS_MIN_FRAC = 0.2       # a seed set of at least this share of the rows of a tile-kernel operand runs the FULL LDS-streamed
+                                    # pass and gathers its rows (row-wave K1 costs ~5x per edge: 6.2 vs 1.19 ms for all of cfg3)
 
 
 def _partials(plan: Plan, D: int, device) -> Optional[torch.Tensor]:
@@ -65,18 +67,35 @@ def agg_fwd(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, self_idx: int
             h_src: torch.Tensor, h_self: Optional[torch.Tensor], *, bias: Optional[torch.Tensor] = None,
             relu: bool = False, row_ids: Optional[torch.Tensor] = None, self_compact: bool = False,
             no_mean: bool = False, out_dtype: Optional[torch.dtype] = None,
-            out: Optional[torch.Tensor] = None, neigh_sum: Optional[torch.Tensor] = None) -> torch.Tensor:
+            out: Optional[torch.Tensor] = None, neigh_sum: Optional[torch.Tensor] = None,
+            src_scaled: Optional[torch.Tensor] = None) -> torch.Tensor:
     """K1 ``wgnn_agg_fwd``: weighted mean of in-neighbours incl. the implicit self-loop.  ``neigh_sum`` (f32 [n_out, D],
-    contiguous) optionally receives the raw neighbour sum of every output row (saved by training for dalpha)."""
+    contiguous) optionally receives the raw neighbour sum of every output row (saved by training for dalpha).
+    ``src_scaled`` (SRC_IS_GENE only): ``alpha[s] * h_src[s]`` already formed (``linear_fwd(..., row_scale=alpha)``) - the
+    LDS-streamed kernel then reads it in place of its own scale pass; the row-wave kernel ignores it."""
     dev = _require_cuda(h_src, h_self, alpha, bias, csr.col)
     h_src = _rowmajor(h_src)
     D = h_src.shape[1]
     if D % 4:
         raise WgnnError(f"feature width {D} must be a multiple of 4")
-    if (TILED_MIN_WORK is not None and row_ids is None and out is None and h_src.dtype == torch.float32
-            and (out_dtype in (None, torch.float32)) and D <= 256 and csr.nnz * D >= TILED_MIN_WORK and csr.ell_cnt is None):
+    tiled_ok = (TILED_MIN_WORK is not None and out is None and h_src.dtype == torch.float32
+                and (out_dtype in (None, torch.float32)) and D <= 256 and csr.nnz * D >= TILED_MIN_WORK and csr.ell_cnt is None)
+    if tiled_ok and row_ids is None:
         return agg_fwd_tiled(csr, csr.tile_plan(tiled_block_rows(D)), alpha, mode, self_idx, h_src, h_self, bias=bias, relu=relu,
-                             no_mean=no_mean, neigh_sum=neigh_sum)
+                             no_mean=no_mean, neigh_sum=neigh_sum, src_scaled=src_scaled)
+    if (tiled_ok and neigh_sum is None and row_ids.shape[0] >= SEED_FULL_PASS_MIN_FRAC * csr.n_rows
+            and (h_self is None or h_self.dtype == torch.float32)):
+        # a LARGE seed set (predict.py:61-88: every test cell is a seed; fit's accuracy() over the training cells): one full
+        # LDS-streamed pass over all rows, then the seeds' rows in seed order.  A compact self table (one row per seed slot)
+        # is spread to row positions first; rows outside the seed set produce values nobody reads.
+        idl = row_ids.to(device=dev, dtype=torch.long)
+        if h_self is not None and self_compact:
+            full_self = torch.empty((csr.n_rows, D), dtype=torch.float32, device=dev)
+            full_self.index_copy_(0, idl, _rowmajor(h_self))
+            h_self = full_self
+        full = agg_fwd_tiled(csr, csr.tile_plan(tiled_block_rows(D)), alpha, mode, self_idx, h_src, h_self, bias=bias, relu=relu,
+                             no_mean=no_mean, src_scaled=src_scaled)
+        return full.index_select(0, idl)
     if h_self is not None:
         h_self = _rowmajor(h_self)
         if h_self.dtype != h_src.dtype or h_self.shape[1] != D:
@@ -243,8 +262,10 @@ def tiled_block_rows(D: int) -> int:
 
 def agg_fwd_tiled(csr: AggCsr, tplan, alpha: Optional[torch.Tensor], mode: int, self_idx: int,
                   h_src: torch.Tensor, h_self: Optional[torch.Tensor], *, bias: Optional[torch.Tensor] = None,
-                  relu: bool = False, no_mean: bool = False, neigh_sum: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """K1t ``wgnn_agg_fwd_tiled``: same result as :func:`agg_fwd`, source table streamed through LDS."""
+                  relu: bool = False, no_mean: bool = False, neigh_sum: Optional[torch.Tensor] = None,
+                  src_scaled: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """K1t ``wgnn_agg_fwd_tiled``: same result as :func:`agg_fwd`, source table streamed through LDS.  ``src_scaled``: the
+    alpha-folded source table (SRC_IS_GENE) when the caller already has it (WGNN_FLAG_SRC_PRESCALED)."""
     dev = _require_cuda(h_src, h_self, alpha, bias, csr.col)
     if h_src.dtype != torch.float32:
         raise WgnnError("tiled kernel is f32 only")
@@ -267,7 +288,12 @@ def agg_fwd_tiled(csr: AggCsr, tplan, alpha: Optional[torch.Tensor], mode: int, 
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record(torch.cuda.current_stream(dev))
     n_long = tplan.long_rows.shape[0]
-    scratch = torch.empty_like(h_src) if mode == SRC_IS_GENE else None
+    scratch = None
+    if mode == SRC_IS_GENE:
+        if src_scaled is not None and src_scaled.shape == h_src.shape and src_scaled.dtype == torch.float32:
+            h_src, flags = src_scaled.contiguous(), flags | _lib.FLAG_SRC_PRESCALED
+        else:
+            scratch = torch.empty_like(h_src)
     rc = _lib.call(dev, "wgnn_agg_fwd_tiled",
         _ptr(csr.rowptr), _ptr(alpha), mode, self_idx,
         _ptr(h_src), h_src.shape[0], _ptr(scratch), _ptr(h_self), h_self.stride(0) if h_self is not None else 0,
@@ -404,14 +430,36 @@ def weighted_sum(csr: AggCsr, h_src: torch.Tensor) -> torch.Tensor:
 # ------------------------------------------------------------------------------------------------
 # dense half of a layer through the C ABI (fp32 matrix cores) - see csrc/wgnn_linear.hip
 # ------------------------------------------------------------------------------------------------
-USE_WGNN_LINEAR = False      # GNN's projections: False = torch.nn.functional.linear (library GEMM), True = wgnn_linear_fwd
+# GNN's projections on the no-grad path: which of them run through wgnn_linear_fwd_ex instead of the library GEMM
+#   "auto"  - fp16-stored inputs (never materialised in fp32), the gene table of a tile-kernel pass (P_g and alpha*P_g from one
+#             kernel, no scale_rows launch) and shapes where the kernel measured faster than hipBLASLt (>= 50k rows, K >= 384:
+#             95 vs 87 TF on 100k x 400 x 256, scratch/linear_time.py);   "always" / "never" - A/B switches
+WGNN_LINEAR = "auto"
+WGNN_LINEAR_MIN_ROWS, WGNN_LINEAR_MIN_K = 50_000, 384
 
 
-def linear_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False) -> torch.Tensor:
-    """``act(x @ weight.T + bias)`` with ``wgnn_linear_fwd`` (v_mfma_f32_32x32x2_f32, exact fp32).  Inference helper: no
-    autograd (training keeps torch's Linear, whose backward is a library GEMM as well)."""
-    dev = _require_cuda(x, weight, bias)
-    x = _rowmajor(x.float()); weight = _rowmajor(weight.float())
+def use_wgnn_linear(x: torch.Tensor, weight: torch.Tensor, dual: bool = False) -> bool:
+    """Routing rule of the model's no-grad projections (see WGNN_LINEAR)."""
+    if WGNN_LINEAR == "never" or not x.is_cuda or x.dim() != 2 or x.shape[1] % 4 or torch.is_grad_enabled() and (
+            x.requires_grad or weight.requires_grad):
+        return False
+    if WGNN_LINEAR == "always":
+        return True
+    return dual or x.dtype == torch.float16 or (x.shape[0] >= WGNN_LINEAR_MIN_ROWS and x.shape[1] >= WGNN_LINEAR_MIN_K)
+
+
+def linear_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,
+               row_scale: Optional[torch.Tensor] = None):
+    """``act(x @ weight.T + bias)`` with ``wgnn_linear_fwd_ex`` (v_mfma_f32_32x32x2_f32, exact fp32).  ``x`` may be stored
+    in fp16 (widened in registers, no fp32 copy).  With ``row_scale`` ([M]) returns ``(out, row_scale[:, None] * out)``,
+    both written by the one kernel.  Inference helper: no autograd (training keeps torch's Linear, whose backward is a
+    library GEMM as well)."""
+    dev = _require_cuda(x, weight, bias, row_scale)
+    if x.dtype not in (torch.float32, torch.float16):
+        x = x.float()
+    x = _rowmajor(x) if x.dtype == torch.float32 else (x if x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 8 == 0
+                                                       else x.contiguous())
+    weight = _rowmajor(weight.float())
     M, K = x.shape
     N = weight.shape[0]
     if weight.shape[1] != K:
@@ -419,12 +467,19 @@ def linear_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
     if K % 4:
         raise WgnnError(f"K = {K} must be a multiple of 4")
     out = torch.empty((M, N), dtype=torch.float32, device=dev)
+    out2 = None
+    if row_scale is not None:
+        row_scale = row_scale.reshape(-1).float().contiguous()
+        if row_scale.shape[0] < M:
+            raise WgnnError("row_scale needs one entry per row of x")
+        out2 = torch.empty((M, N), dtype=torch.float32, device=dev)
     if bias is not None:
         bias = bias.float().contiguous()
-    rc = _lib.call(dev, "wgnn_linear_fwd", _ptr(x), x.stride(0), _ptr(weight), weight.stride(0), _ptr(bias), _ptr(out),
-                   out.stride(0), M, N, K, _lib.FLAG_RELU if relu else 0, _stream(dev))
-    _lib.check(rc, "wgnn_linear_fwd")
-    return out
+    rc = _lib.call(dev, "wgnn_linear_fwd_ex", _ptr(x), _dtype_code(x), x.stride(0), _ptr(weight), weight.stride(0), _ptr(bias),
+                   _ptr(out), out.stride(0), _ptr(row_scale), _ptr(out2), N if out2 is not None else 0, M, N, K,
+                   _lib.FLAG_RELU if relu else 0, _stream(dev))
+    _lib.check(rc, "wgnn_linear_fwd_ex")
+    return out if out2 is None else (out, out2)
 
 
 WGRAD_MIN_ROWS = 16384       # from this many rows on, the weight gradient of a Linear runs through wgnn_linear_wgrad

@@ -59,7 +59,7 @@ class ShardedWgnn:
         ``global_stats`` = (deg, sum) over ALL shards; when None and a process group is up they are all-reduced."""
         rank, world = D.world()
         g = CellGeneGraph.from_device_csr(rowptr, col, raw, num_genes, chunk)
-        if world > 1 or global_stats is not None:
+        if world > 1 or global_stats is not None or D.comm_active():
             # gene side: w = deg_glob * x / sum_glob over ALL ranks' cells (preprocess_internal.py:17-23)
             gc = g.gc
             deg_loc, sum_loc = ShardedWgnn.gene_stats(col, raw, num_genes)
@@ -75,7 +75,7 @@ class ShardedWgnn:
             gc._tile_plan = None
             world = max(world, 2)
         sizes, pad_nnz = None, None
-        if D.world()[1] > 1:
+        if D.comm_active():
             import torch.distributed as tdist
             mine = torch.tensor([g.num_cells, g.cg.nnz], dtype=torch.long, device=col.device)
             every = [torch.zeros_like(mine) for _ in range(D.world()[1])]
@@ -83,7 +83,7 @@ class ShardedWgnn:
             sizes = [int(t[0].item()) for t in every]
             pad_nnz = max(int(t[1].item()) for t in every)          # rank-invariant width decision (see __init__)
         eng = ShardedWgnn(model, g, world, sizes, pad_nnz, seed)
-        if D.world()[1] > 1:                                        # one-time check: equal carried widths on every rank
+        if D.comm_active():                                         # one-time check: equal carried widths on every rank
             import torch.distributed as tdist
             w = torch.tensor([W.shape[0] for W, _ in eng._weights()[:-1]], dtype=torch.long, device=col.device)
             every = [torch.zeros_like(w) for _ in range(D.world()[1])]

@@ -67,11 +67,13 @@ def _worker(rank, world, port, out_dir, cells=90):
         weights = [(sd[f"layers.{i}.fc_neigh.weight"], sd[f"layers.{i}.fc_neigh.bias"]) for i in range(2)] + \
                   [(sd["linear.weight"], sd["linear.bias"])]
         feats = torch.from_numpy(c["feats"]).double()
-        logits = D.sharded_forward(weights, None, feats[:G], feats[G + lo:G + hi], ops, 2, gather_logits=True)
+        sizes = [D.shard_range(C, r, world)[1] - D.shard_range(C, r, world)[0] for r in range(world)]
+        with pytest.raises(ValueError):                  # no per-forward size exchange: the sizes are a build-time fact
+            D.sharded_forward(weights, None, feats[:G], feats[G + lo:G + hi], ops, 2, gather_logits=True)
+        logits = D.sharded_forward(weights, None, feats[:G], feats[G + lo:G + hi], ops, 2, True, sizes)
         full = O.csr_forward(sd, ref, c["feats"].astype(np.float64), 2, dtype=np.float64)
         np.testing.assert_allclose(logits.numpy(), full, atol=1e-6)          # every rank holds ALL cells' logits, in order
         # shard sizes known at graph build: the concat needs no size exchange (equal shards -> one all_gather_into_tensor)
-        sizes = [D.shard_range(C, r, world)[1] - D.shard_range(C, r, world)[0] for r in range(world)]
         l2 = D.sharded_forward(weights, None, feats[:G], feats[G + lo:G + hi], ops, 2, True, sizes)
         assert torch.equal(l2, logits)
         res = D.sharded_forward(weights, None, feats[:G], feats[G + lo:G + hi], ops, 2, True, sizes, async_gather=True)

@@ -32,7 +32,7 @@ def test_library_loaded_and_gpu_present():
     assert torch.cuda.is_available()
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
     from scdeepsort_amd import _lib
-    assert _lib.lib().wgnn_version() == 101
+    assert _lib.lib().wgnn_version() == 200
 
 
 def test_kat_2x2_on_gpu():
@@ -1290,3 +1290,84 @@ def test_linear_weight_gradient_on_the_matrix_cores(M, N, K):
         np.testing.assert_allclose(Ws[0].grad.cpu().numpy(), Ws[1].grad.cpu().numpy(), atol=2e-3 * np.sqrt(M / 20000), rtol=1e-4)
         np.testing.assert_allclose(xs[0].grad.cpu().numpy(), xs[1].grad.cpu().numpy(), atol=1e-5)
         np.testing.assert_allclose(bs[0].grad.cpu().numpy(), bs[1].grad.cpu().numpy(), atol=1e-3, rtol=1e-5)
+
+
+# ---- large seed sets: predict.py:61-88 makes EVERY test cell a seed -----------------------------
+@pytest.mark.parametrize("n_layers,order", [(1, "auto"), (2, "project_first"), (2, "aggregate_first")])
+def test_large_seed_set_runs_the_lds_streamed_kernel_and_matches_oracle(n_layers, order, monkeypatch):
+    """A seed set covering >= ops.SEED_FULL_PASS_MIN_FRAC of the rows of a tile-kernel operand must NOT fall to the row-wave
+    kernel: the full LDS-streamed pass runs and the seeds' rows are gathered (shuffled order, a repeated seed, test cells
+    of a predict graph).  Logits and every gradient against the oracle's NodeFlow emulation on the same seeds."""
+    from scdeepsort_amd import ops
+    c = small_case(cells=120, genes=64, dim=24, hidden=16, n_classes=5, seed=31, test_cells=10)
+    sd = O.init_params(24, 16, 5, n_layers, 64, seed=8)
+    rg = O.build_reference_graph(c["expr"], c["support_mask"])
+    rng = np.random.default_rng(3)
+    seeds = rng.permutation(np.arange(64, 64 + 120))[:90]
+    seeds[7] = seeds[3]                                                    # a repeated seed
+    labels = torch.from_numpy(rng.integers(0, 5, len(seeds)))
+    loss, grads, want = O.loss_and_grads(sd, rg, torch.from_numpy(c["feats"]), seeds, labels, n_layers)
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
+    monkeypatch.setattr(ops, "TILED_MIN_WORK", 1)
+    m = make_model(sd, 24, 16, 5, n_layers, 64, order)
+    ops.PROFILE = []
+    try:
+        logits = m(g, dev(c["feats"]), seeds=torch.from_numpy(seeds).to(DEV))
+        kernels = [dict(zip(t[::2], t[1::2]))["kernel"] for t, _, _ in ops.PROFILE]
+    finally:
+        ops.PROFILE = None
+    assert kernels and set(kernels) == {"agg_tiled_flat4"}, kernels          # no row-wave launch anywhere in the forward
+    np.testing.assert_allclose(logits.detach().cpu().numpy(), want.detach().numpy(), atol=TOL)
+    l = F.cross_entropy(logits, labels.to(DEV), reduction="sum")
+    l.backward()
+    assert l.item() == pytest.approx(float(loss), rel=1e-5)
+    for k, p in m.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), grads[k].numpy(), atol=2e-4, rtol=1e-3, err_msg=k)
+    # a SMALL batch on the same operand keeps the row-wave kernel and its bit-identical batching property
+    few = torch.from_numpy(seeds[:5]).to(DEV)
+    with torch.no_grad():
+        a = m(g, dev(c["feats"]), seeds=few)
+        b = m(g, dev(c["feats"]), seeds=torch.from_numpy(seeds[:9]).to(DEV))[:5]
+    assert torch.equal(a, b)
+    np.testing.assert_allclose(a.cpu().numpy(), want.detach().numpy()[:5], atol=TOL)
+
+
+def test_all_cells_as_shuffled_seeds_at_cfg3_size():
+    """GNN.forward(seeds = all 100k cfg3 cells, shuffled) - the shape of DeepSortPredictor.predict at atlas scale - against
+    the seeds=None pass: same logits (<= 1e-4) in seed order, only LDS-streamed launches, within 1.2x of its time."""
+    from scdeepsort_amd import ops, synthetic as S
+    cfg = S.CONFIGS["cfg3"]
+    G, C = cfg.genes, cfg.cells
+    rp, col, val = S.synth_expression(C, G, device=DEV)
+    g = sda.CellGeneGraph.from_device_csr(rp, col, val, G)
+    del rp, col, val
+    torch.manual_seed(2)
+    m = sda.GNN(cfg.dense_dim, cfg.hidden, cfg.n_classes, 2, G, activation=F.relu).to(DEV).eval()
+    with torch.no_grad():
+        m.alpha.uniform_(0.5, 1.5)
+    feats = S.synth_features(G + C, cfg.dense_dim, device=DEV)
+    perm = torch.randperm(C, device=DEV)
+    seeds = perm + G
+
+    def timed(fn, reps=5):
+        for _ in range(2):
+            out = fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            out = fn()
+        e1.record(); torch.cuda.synchronize()
+        return out, e0.elapsed_time(e1) / reps
+
+    with torch.no_grad():
+        full, t_full = timed(lambda: m(g, feats))
+        ops.PROFILE = []
+        try:
+            m(g, feats, seeds=seeds)
+            kernels = {dict(zip(t[::2], t[1::2]))["kernel"] for t, _, _ in ops.PROFILE}
+        finally:
+            ops.PROFILE = None
+        sub, t_seeds = timed(lambda: m(g, feats, seeds=seeds))
+    assert kernels == {"agg_tiled_flat4"}, kernels
+    assert (sub - full[perm]).abs().max().item() < TOL
+    assert t_seeds < 1.2 * t_full, (t_seeds, t_full)
