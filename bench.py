@@ -75,6 +75,12 @@ def cpu_baseline(graph, model, feats_g, feats_c, gpu_logits, cfg):
     every.append({"name": "port_c_openmp_project_first", "value": round(C / t, 1), "unit": "cells/s", "cores": CO.num_threads(),
                   "s_per_forward": round(t, 3), "sample": f"full {cfg.name} graph, best of {reps}; C/OpenMP aggregation of the "
                   "projected H-wide rows (the GPU path's order) + torch Linear", "max_abs_err_vs_gpu": float(np.abs(l1 - gpu).max())})
+    t, reps, l3 = best_of(lambda: CO.forward(sd, ocg, feats, model.n_layers, order="project_first_blocked"), 5, 6.0)
+    every.append({"name": "port_c_openmp_cache_blocked", "value": round(C / t, 1), "unit": "cells/s", "cores": CO.num_threads(),
+                  "s_per_forward": round(t, 4), "sample": f"full {cfg.name} graph, best of {reps}; C/OpenMP aggregation tiled like the "
+                  "GPU kernel (256 destination rows x 256 source rows per step, accumulators and the source block L2-resident, "
+                  "AVX-512 body picked at load time) on the projected H-wide rows + torch Linear",
+                  "max_abs_err_vs_gpu": float(np.abs(l3 - gpu).max())})
     t, reps, l2 = best_of(lambda: CB.b2_torch_csr_forward(sd, ocg, feats, model.n_layers), 3, 10.0)
     every.append({"name": "B2_torch_csr_spmm", "value": round(C / t, 1), "unit": "cells/s", "cores": threads,
                   "s_per_forward": round(t, 3), "sample": f"full {cfg.name} graph, best of {reps}; torch.sparse CSR SpMM + "
@@ -87,9 +93,18 @@ def cpu_baseline(graph, model, feats_g, feats_c, gpu_logits, cfg):
                             f"{b1['s_measured']:.2f} s) with materialised [E_b, D] messages + index_add_ (gnn.py:47-65, "
                             f"train.py:71-80 restated, not DGL); EXTRAPOLATED by seconds per edge-float to the "
                             f"{model.n_layers}-layer forward", "restatements_agree_max_abs": b1["check_err"]})
+    # algorithmic flops of one forward (F_pass = 2 (nnz + R) D + 2 R D_in D_out, project-first widths)
+    Hh, Din = model.layers[0].fc_neigh.weight.shape
+    fl, d_in = 0.0, Din
+    for i in range(model.n_layers):
+        fl += 2.0 * (G + C) * d_in * Hh + 2.0 * (A_cg.nnz + C) * Hh + (2.0 * (A_gc.nnz + G) * Hh if i < model.n_layers - 1 else 0.0)
+        d_in = Hh
+    for e in every:
+        e["GFLOPs"] = round(fl / e["s_per_forward"] / 1e9, 1)
     top = max(every, key=lambda e: e["value"])
     return {"value": top["value"], "unit": "cells/s", "cores": top["cores"], "kind": "port", "strongest": top["name"],
             "sample": top["sample"] + f"; host has {os.cpu_count()} logical CPUs", "gpu_vs_cpu_max_abs_err": err,
+            "GFLOPs": top["GFLOPs"], "forward_GFLOP": round(fl / 1e9, 1),
             "all": every}
 
 
@@ -133,14 +148,15 @@ def build_workload(cfg, mode, rank, world, dev, S, shard_range):
     return mine, feats_g, feats_c[lo:hi].clone(), cfg.cells, whole
 
 
-def timed_steps(engine, feats_g, feats_c, steps, warmup, world, dev, profile=True):
+def timed_steps(engine, feats_g, feats_c, steps, warmup, world, dev, profile=True, step=None):
     """W untimed + EXACTLY K timed forwards between barrier + synchronize on both sides; returns (max-over-ranks seconds,
-    local seconds, per-launch HIP-event records, last output)."""
+    local seconds, per-launch HIP-event records, last output).  ``step``: replaces the eager forward (hipGraph replay)."""
     from scdeepsort_amd import ops
 
-    def step():
+    def eager():
         with torch.no_grad():
             return engine.forward(feats_g, feats_c, async_gather=world > 1)    # concat of step i overlaps step i+1
+    step = step or eager
 
     out = None
     for _ in range(warmup):
@@ -179,6 +195,8 @@ def main():
     ap.add_argument("--scaling", choices=("strong", "weak"), default=os.environ.get("WGNN_BENCH_SCALING", "strong"),
                     help="strong (default): ONE cfg-sized job, its cells sharded over the ranks (BASELINE cfg3/cfg4/cfg5); "
                          "weak: every rank owns a cfg-sized shard")
+    ap.add_argument("--graphed", choices=("auto", "on", "off"), default="auto",
+                    help="replay the forward as ONE hipGraph launch per step (auto: launch-bound configs, i.e. small graphs at N = 1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the weak-scaling / sustained secondary measurements")
     args = ap.parse_args()
@@ -228,8 +246,21 @@ def main():
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
 
-    dt, dt_local, prof, out = timed_steps(engine, feats_g, feats_c, args.steps, args.warmup, world, dev)
+    # launch-bound configs (cfg2: ~25 launches of a few us each): the same forward captured once and replayed as one hipGraph
+    # launch per step (scdeepsort_amd.graphed.GraphedForward); per-launch HIP events cannot be recorded inside a replay, so
+    # the roofline's per-kernel durations come from a short eager pass of the same forward outside the timed region
+    graphed = world == 1 and (args.graphed == "on" or (args.graphed == "auto" and cfg.cells * cfg.genes <= 100_000_000))
+    step_fn = None
+    if graphed:
+        from scdeepsort_amd.graphed import GraphedForward
+        gf = GraphedForward(model, engine.graph, torch.cat([feats_g, feats_c]))
+        step_fn = lambda: gf()
+    dt, dt_local, prof, out = timed_steps(engine, feats_g, feats_c, args.steps, args.warmup, world, dev, step=step_fn)
     assert torch.isfinite(out).all()
+    eager_ms = None
+    if graphed:
+        dt_e, _, prof, _ = timed_steps(engine, feats_g, feats_c, args.steps, 1, world, dev)
+        eager_ms = round(dt_e / args.steps * 1e3, 4)
     ms_per_step = dt / args.steps * 1e3
     value = total_cells / (dt / args.steps)
 
@@ -331,7 +362,7 @@ def main():
     sustained, weak = None, None
     if not args.no_secondary:
         n_sus = max(args.steps, min(2000, int(1.2 / max(dt / args.steps, 1e-5))))
-        dt_s, _, _, _ = timed_steps(engine, feats_g, feats_c, n_sus, 0, world, dev, profile=False)
+        dt_s, _, _, _ = timed_steps(engine, feats_g, feats_c, n_sus, 0, world, dev, profile=False, step=step_fn)
         sustained = {"steps": n_sus, "ms_per_step": round(dt_s / n_sus * 1e3, 4), "value": round(total_cells / (dt_s / n_sus), 1),
                      "unit": "cells/s"}
         if world > 1 and mode == "strong" and not cfg.total_cells:
@@ -362,6 +393,7 @@ def main():
                            "cells_total": total_cells, "cells_this_rank": C,
                            "nnz_per_gpu": per_gpu[0]["nnz"] if per_gpu else roofline["passes"][0]["nnz"],
                            "parallelism": f"cell-shard x{world}", "setup_s": round(t_setup, 1), "communicator": comm,
+                           "step_launch": "hipGraph replay (1 launch per step)" if graphed else "eager", "eager_ms_per_step": eager_ms,
                            "sharded_vs_unsharded": self_check},
                 "roofline": roofline, "cpu_baseline": cpu, "sustained": sustained, "weak_scaling": weak}
         print(json.dumps(line))

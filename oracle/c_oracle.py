@@ -43,6 +43,21 @@ def aggregate(rowptr, col, val, alpha, mode, self_idx, h_src, h_self):
     return out
 
 
+def aggregate_blocked(rowptr, col, val, alpha, mode, self_idx, h_src, h_self, tile_rows=256, block_rows=256):
+    """Cache-blocked form of :func:`aggregate` (tile of destination rows x block of source rows, see wgnn_oracle.c)."""
+    rowptr = np.ascontiguousarray(rowptr, np.int32); col = np.ascontiguousarray(col, np.int32)
+    val = np.ascontiguousarray(val, np.float32); alpha = np.ascontiguousarray(alpha, np.float32).ravel()
+    h_src = np.ascontiguousarray(h_src, np.float32); h_self = np.ascontiguousarray(h_self, np.float32)
+    R, D = h_self.shape
+    out = np.empty((R, D), np.float32)
+    pre = np.empty_like(h_src) if mode == 0 else h_src
+    lib().oracle_aggregate_blocked(_p(rowptr), _p(col), _p(val), _p(alpha), C.c_int(mode), C.c_int32(self_idx),
+                                   _p(h_src), C.c_int64(h_src.shape[1]), _p(h_self), C.c_int64(D), _p(out), C.c_int64(D),
+                                   C.c_int64(R), C.c_int64(h_src.shape[0]), C.c_int32(D), C.c_int32(tile_rows),
+                                   C.c_int32(block_rows), _p(pre))
+    return out
+
+
 def normalize_rows(rowptr, val):
     rowptr = np.ascontiguousarray(rowptr, np.int32); val = np.ascontiguousarray(val, np.float32)
     out = np.empty_like(val)
@@ -65,14 +80,15 @@ def forward(sd, cg, features, n_layers, order="aggregate_first"):
     alpha = sd["alpha"].detach().numpy().ravel().astype(np.float32)
     Hg = np.ascontiguousarray(features[:G], np.float32); Hc = np.ascontiguousarray(features[G:], np.float32)
     A_cg, A_gc = cg.A_cg, cg.A_gc
-    if order == "project_first":
+    if order in ("project_first", "project_first_blocked"):
+        agg = aggregate if order == "project_first" else aggregate_blocked
         for i in range(n_layers):
             last = i == n_layers - 1
             W, b = sd[f"layers.{i}.fc_neigh.weight"].float(), sd[f"layers.{i}.fc_neigh.bias"].float().numpy()
             Pg = F.linear(torch.from_numpy(Hg), W).numpy(); Pc = F.linear(torch.from_numpy(Hc), W).numpy()
-            Zc = aggregate(A_cg.indptr, A_cg.indices, A_cg.data, alpha, 0, G + 1, Pg, Pc)
+            Zc = agg(A_cg.indptr, A_cg.indices, A_cg.data, alpha, 0, G + 1, Pg, Pc)
             if not last:
-                Zg = aggregate(A_gc.indptr, A_gc.indices, A_gc.data, alpha, 1, G, Pc, Pg)
+                Zg = agg(A_gc.indptr, A_gc.indices, A_gc.data, alpha, 1, G, Pc, Pg)
                 Hg = np.maximum(Zg + b, 0, out=Zg)
             Hc = np.maximum(Zc + b, 0, out=Zc)
         return F.linear(torch.from_numpy(Hc), sd["linear.weight"].float(), sd["linear.bias"].float()).numpy()

@@ -233,12 +233,12 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
     const int lane16 = lane * 16, row_mask = ~1023;
     // global -> LDS DMA of `rows` source rows starting at global row r0 into LDS buffer `buf`: one 1 KiB row per
     // wave-instruction, wave w takes rows w, w+16, ...  Scalar base + lane offset addressing: no VALU, 4 SALU per row.
-    auto fill_rows = [&](int r0, int rows, int buf) {
-        const int np = rows > wave ? (rows - wave + kTW - 1) / kTW : 0;        // <= 5 for blocks of <= 80 rows
+    auto fill_rows = [&](int r0, int rows, int buf, int nw) {                    // nw = kTW: wave w takes rows w, w+16, ...
+        const int np = rows > wave ? (rows - wave + nw - 1) / nw : 0;          // <= 5 for blocks of <= 80 rows
         if (np == 0) return;
         const char* g = reinterpret_cast<const char*>(a.src) + ((size_t)r0 + wave) * g_row;
         const int l = (int)(size_t)smem + buf * buf_bytes + wave * row_bytes;
-        if (DBG && (dbg & kDbgFillToVgpr)) {                  // ablation: identical loads, no LDS writes
+        if (DBG && (dbg & kDbgFillToVgpr)) {                  // ablation: identical loads, no LDS writes (16-wave form only)
 #define WGNN_FILLV_NEXT(K)                                                                                  \
         "s_cmp_lt_u32 %[np], " #K "\n\ts_cbranch_scc1 .Lw4_fv_%=\n\t"                                        \
         "s_add_u32 s94, s94, 0x4000\n\ts_addc_u32 s95, s95, 0\n\t"                                          \
@@ -256,19 +256,19 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
         // its 1 KiB LDS slot; the slot's tail is never read by a lane that is stored)
 #define WGNN_FILL_NEXT(K)                                                                                   \
         "s_cmp_lt_u32 %[np], " #K "\n\ts_cbranch_scc1 .Lw4_fd_%=\n\t"                                        \
-        "s_add_u32 m0, m0, 0x4000\n\ts_add_u32 s94, s94, s90\n\ts_addc_u32 s95, s95, 0\n\t"               \
+        "s_add_u32 m0, m0, %[ms]\n\ts_add_u32 s94, s94, s90\n\ts_addc_u32 s95, s95, 0\n\t"               \
         "global_load_lds_dwordx4 %[vo], s[94:95]\n\t"
-        asm volatile("s_mov_b64 s[92:93], exec\n\ts_sub_u32 s91, 64, %[n4]\n\ts_lshl_b32 s90, %[n4], 8\n\t"   // s90 = 16 rows x D*4 B
+        asm volatile("s_mov_b64 s[92:93], exec\n\ts_sub_u32 s91, 64, %[n4]\n\ts_mul_i32 s90, %[n4], %[gs]\n\t"   // s90 = nw rows x D*4 B
                      "s_lshr_b64 exec, s[92:93], s91\n\t"                                                       // lanes 0 .. D/4-1
                      "s_mov_b64 s[94:95], %[g]\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\t"
                      "global_load_lds_dwordx4 %[vo], s[94:95]\n\t"
                      WGNN_FILL_NEXT(2) WGNN_FILL_NEXT(3) WGNN_FILL_NEXT(4) WGNN_FILL_NEXT(5)
                      ".Lw4_fd_%=:\n\ts_mov_b64 exec, s[92:93]"
-                     ::[g] "s"(g), [l] "s"(l), [vo] "v"(lane16), [np] "s"(np), [n4] "s"(n4)
+                     ::[g] "s"(g), [l] "s"(l), [vo] "v"(lane16), [np] "s"(np), [n4] "s"(n4), [ms] "s"(nw * row_bytes), [gs] "s"(nw * 16)
                      : "m0", "memory", "scc", "s90", "s91", "s92", "s93", "s94", "s95");
 #undef WGNN_FILL_NEXT
     };
-    auto fill = [&](int b) { fill_rows(cb + b * kKB, min(kKB, ce - (cb + b * kKB)), b & 1); };
+    auto fill = [&](int b) { fill_rows(cb + b * kKB, min(kKB, ce - (cb + b * kKB)), b & 1, kTW); };
     // RIGHT-aligned entry chunk of segment [s, e): with n = min(64, e - s) entries, lane j <- entry s + j - (64 - n);
     // the lanes in front of the chunk replicate its first entry (consume() zeroes their weight).  Always issues exactly
     // one load (the vmcnt bookkeeping depends on it), also for an empty segment (then: any valid entry).
@@ -333,7 +333,7 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
         asm volatile("v_readfirstlane_b32 %0, v32\n\tv_readfirstlane_b32 %1, v33" : "=s"(ns), "=s"(ne)::"memory");
         seg_load(segp);
         segp += kTW;
-        if (do_fill) fill_rows(fill_row, kKB, par ^ 1);
+        if (do_fill) fill_rows(fill_row, kKB, par ^ 1, kTW);
         fill_row += kKB;
         chunk_issue(nxt_set, ns, ne);
         if (do_comp) compute(cur_set, cs, ce0, (int)(size_t)smem + par * buf_bytes);

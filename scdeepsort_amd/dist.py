@@ -146,8 +146,10 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
             if compact:
                 m_c = m_c[seeds_local.long()]
             h_g, h_c = h_g.to(m_g.dtype) * m_g, h_c.to(m_c.dtype) * m_c
-        p_g = linear(h_g.to(W.dtype), W)
-        p_c = linear(h_c.to(W.dtype), W)
+        if getattr(linear, "widens_fp16", False):       # ops.linear: fp16-stored rows are widened inside the GEMM's loader
+            p_g, p_c = linear(h_g, W), linear(h_c, W)
+        else:
+            p_g, p_c = linear(h_g.to(W.dtype), W), linear(h_c.to(W.dtype), W)
         if last:                                        # a seed mini-batch only needs its own rows of the last layer
             h_c = ops.cells_layer(p_g, p_c, b, relu) if rows is None else ops.cells_layer(p_g, p_c, b, relu, rows, compact)
             break

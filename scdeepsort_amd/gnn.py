@@ -30,6 +30,7 @@ import torch.nn.functional as F
 
 from ._lib import DST_IS_GENE, SRC_IS_GENE
 from .graph import CellGeneGraph
+from . import ops as _ops
 from .ops import linear as _linear, weighted_mean_aggregate, weighted_sum
 
 
@@ -103,8 +104,11 @@ class GNN(nn.Module):
         fuse_relu = _is_relu(act)
         if self.dropout is not None:                       # node rows, before the gather (gnn.py:62-64)
             h_g, h_c = self.dropout(h_g), self.dropout(h_c)
-        if h_g.dtype != W.dtype:                           # fp16-stored features (BASELINE cfg5): widened on the way
-            h_g, h_c = h_g.to(W.dtype), h_c.to(W.dtype)     # into the fp32 projection (fp16-rounded inputs, fp32 accumulate)
+        # fp16-stored features (BASELINE cfg5) meet fp32 weights: fp16-rounded inputs, fp32 multiply-accumulate.  On the no-grad
+        # project-first path `ops.linear` widens them in the GEMM's loader (wgnn_linear_fwd_ex) - no fp32 copy of [C, D_in] in
+        # HBM; everywhere else they are converted here.
+        if h_g.dtype != W.dtype and not (project_first and h_g.dtype == torch.float16 and _ops.use_wgnn_linear(h_c, W)):
+            h_g, h_c = h_g.to(W.dtype), h_c.to(W.dtype)
 
         def finish(x):
             if act is not None and not fuse_relu:
@@ -115,20 +119,29 @@ class GNN(nn.Module):
 
         compact = cell_rows is not None
         if project_first:
-            p_g = _linear(h_g, W)
+            # when the cells<-genes pass will run LDS-streamed (it needs alpha[g] * P_g[g] as its source table) and nothing
+            # here is differentiated, ONE kernel writes both P_g and its alpha-folded copy (no scale_rows launch)
+            p_g_scaled = None
+            tiled_cells = (_ops.TILED_MIN_WORK is not None and Hp <= 256 and g.cg.nnz * Hp >= _ops.TILED_MIN_WORK
+                           and g.cg.ell_cnt is None and not torch.is_grad_enabled()
+                           and (cell_rows is None or cell_rows.shape[0] >= _ops.SEED_FULL_PASS_MIN_FRAC * g.cg.n_rows))
+            if tiled_cells and _ops.use_wgnn_linear(h_g, W, dual=True):
+                p_g, p_g_scaled = _ops.linear_fwd(h_g, W, row_scale=self.alpha.reshape(-1)[:G])
+            else:
+                p_g = _linear(h_g, W)
             need_all_cells = (want_genes or not compact) and not h_c_compact
             p_c_all = _linear(h_c, W) if need_all_cells else None
             self_compact = compact
             if h_c_compact:
-                p_c_self = F.linear(h_c, W)
+                p_c_self = _linear(h_c, W)
             elif not compact:
                 p_c_self = p_c_all
             elif p_c_all is not None:                    # every cell's projection exists (the next layer's genes read it):
                 p_c_self, self_compact = p_c_all, False  # the seeds' self rows are read in place, no [B, H] gather
             else:
-                p_c_self = F.linear(h_c[cell_rows.long()], W)
+                p_c_self = _linear(h_c[cell_rows.long()], W)
             out_c = weighted_mean_aggregate(g.cg, self.alpha, SRC_IS_GENE, G + 1, p_g, p_c_self, bias=b,
-                                            relu=fuse_relu, row_ids=cell_rows, self_compact=self_compact)
+                                            relu=fuse_relu, row_ids=cell_rows, self_compact=self_compact, src_scaled=p_g_scaled)
             out_g = None
             if want_genes:
                 out_g = weighted_mean_aggregate(g.gc, self.alpha, DST_IS_GENE, G, p_c_all, p_g, bias=b, relu=fuse_relu)

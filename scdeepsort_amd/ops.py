@@ -400,7 +400,13 @@ class WeightedMeanAggregate(torch.autograd.Function):
 
 def weighted_mean_aggregate(csr: AggCsr, alpha: torch.Tensor, mode: int, self_idx: int, h_src: torch.Tensor,
                             h_self: Optional[torch.Tensor], bias: Optional[torch.Tensor] = None, relu: bool = False,
-                            row_ids: Optional[torch.Tensor] = None, self_compact: bool = False) -> torch.Tensor:
+                            row_ids: Optional[torch.Tensor] = None, self_compact: bool = False,
+                            src_scaled: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Differentiable K1 (+ fused bias / ReLU).  ``src_scaled``: the caller's alpha-folded source table - only meaningful when
+    nothing is recorded for backward (it is a function of alpha and h_src that autograd does not see)."""
+    if src_scaled is not None and not torch.is_grad_enabled():
+        return agg_fwd(csr, alpha, mode, self_idx, h_src, h_self, bias=bias, relu=relu, row_ids=row_ids,
+                       self_compact=self_compact, src_scaled=src_scaled)
     return WeightedMeanAggregate.apply(h_src, h_self, alpha, bias, csr, mode, self_idx, relu, row_ids, self_compact)
 
 
@@ -526,9 +532,17 @@ class _LinearBigM(torch.autograd.Function):
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """``F.linear`` for the model's projections; in training on many rows the weight gradient uses the matrix-core kernel."""
+    """``F.linear`` for the model's projections; in training on many rows the weight gradient uses the matrix-core kernel;
+    with nothing to differentiate, fp16-stored inputs and the shapes where it wins run through ``wgnn_linear_fwd_ex``."""
+    if use_wgnn_linear(x, weight):
+        return linear_fwd(x, weight, bias)
+    if x.dtype != weight.dtype:
+        x = x.to(weight.dtype)
     if (torch.is_grad_enabled() and weight.requires_grad and x.is_cuda and x.dim() == 2 and x.shape[0] >= WGRAD_MIN_ROWS
             and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.shape[0] % 4 == 0
             and weight.shape[1] % 4 == 0):
         return _LinearBigM.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight, bias)
+
+
+linear.widens_fp16 = True

@@ -42,6 +42,8 @@ def test_header_enums_match_python():
     assert (val("WGNN_F32"), val("WGNN_F16")) == (_lib.F32, _lib.F16)
     assert (val("WGNN_FLAG_RELU"), val("WGNN_FLAG_NO_MEAN"), val("WGNN_FLAG_NO_SELF"), val("WGNN_FLAG_SELF_COMPACT")) == \
            (_lib.FLAG_RELU, _lib.FLAG_NO_MEAN, _lib.FLAG_NO_SELF, _lib.FLAG_SELF_COMPACT)
+    assert (val("WGNN_FLAG_ROWPTR_I64"), val("WGNN_FLAG_SRC_PRESCALED")) == (_lib.FLAG_ROWPTR_I64, _lib.FLAG_SRC_PRESCALED)
+    assert val("WGNN_VERSION") // 100 == _lib.ABI_MAJOR
 
 
 def test_argument_validation_returns_error_codes_without_gpu():
@@ -58,6 +60,15 @@ def test_argument_validation_returns_error_codes_without_gpu():
     assert fwd(n_items=3) == -1                 # items missing
     assert fwd(dtype=5) == -3
     assert lib.wgnn_normalize_rows(None, one, one, None, 4, None) == -1
+    assert lib.wgnn_normalize_rows_i64(None, one, one, None, 4, None) == -1
+    lin = lambda **k: lib.wgnn_linear_fwd_ex(k.get("x", one), k.get("dt", 0), 8, one, 8, None, k.get("out", one), 8, k.get("rs"),
+                                             k.get("o2"), 8, 4, 8, k.get("K", 8), k.get("fl", 0), None)
+    assert lin(K=6) == -2                        # K % 4
+    assert lin(dt=3) == -1                       # unknown storage type
+    assert lin(rs=one) == -1 and lin(o2=one) == -1      # row_scale and out_scaled come together
+    assert lin(out=None) == -1                   # no output at all
+    assert lin(fl=2) == -1                       # only WGNN_FLAG_RELU
+    assert lin(x=C.c_void_p(8), dt=1, K=0) == -1
     assert lib.wgnn_normalize_rows(one, one, one, None, 0, None) == 0      # empty input is a no-op
     for code in (-1, -2, -3, -4, -5, -6):
         assert len(lib.wgnn_last_error_string(code)) > 3

@@ -1371,3 +1371,103 @@ def test_all_cells_as_shuffled_seeds_at_cfg3_size():
     assert kernels == {"agg_tiled_flat4"}, kernels
     assert (sub - full[perm]).abs().max().item() < TOL
     assert t_seeds < 1.2 * t_full, (t_seeds, t_full)
+
+
+# ---- ABI 0.2.0: fp16-stored inputs / row-scaled second output of the dense half, int64 row pointers -----------------
+@pytest.mark.parametrize("M,N,K", [(5, 16, 8), (300, 200, 52), (2049, 256, 400)])
+@pytest.mark.parametrize("half_in", [False, True])
+def test_linear_fwd_ex_fp16_input_and_row_scaled_second_output(M, N, K, half_in):
+    """wgnn_linear_fwd_ex: x stored in fp16 is widened in the loader (fp16-rounded inputs, fp32 multiply-accumulate; the
+    reference against the SAME rounded inputs in fp64), and out_scaled[m] = row_scale[m] * out[m] from the same accumulators."""
+    from scdeepsort_amd import ops
+    rng = np.random.default_rng(M * 7 + N + K)
+    x = rng.standard_normal((M, K)).astype(np.float32); w = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N).astype(np.float32); sc = (rng.random(M) + 0.5).astype(np.float32)
+    xd = dev(x).half() if half_in else dev(x)
+    out, out2 = ops.linear_fwd(xd, dev(w), dev(b), relu=True, row_scale=dev(sc))
+    xin = xd.float().cpu().numpy().astype(np.float64)
+    want = np.maximum(xin @ w.astype(np.float64).T + b, 0)
+    np.testing.assert_allclose(out.cpu().numpy(), want, atol=2e-5)
+    np.testing.assert_allclose(out2.cpu().numpy(), want * sc[:, None], atol=3e-5)
+    assert torch.equal(out2, out * dev(sc)[:, None])                       # the same fp32 product, bit for bit
+    single = ops.linear_fwd(xd, dev(w), dev(b), relu=True)
+    assert torch.equal(single, out)
+
+
+@pytest.mark.parametrize("n_layers,seeded", [(2, False), (2, True), (1, True)])
+def test_nograd_forward_through_wgnn_linear_and_prescaled_source(n_layers, seeded, monkeypatch):
+    """The no-grad forward with the projections on wgnn_linear_fwd_ex (P_g and alpha * P_g from one kernel -> the tile kernel's
+    WGNN_FLAG_SRC_PRESCALED, fp16-stored features widened in the loader) against the library-GEMM route and the oracle."""
+    from scdeepsort_amd import ops
+    c = small_case(cells=150, genes=80, dim=24, hidden=20, n_classes=5, seed=41, test_cells=12)
+    sd = O.init_params(24, 20, 5, n_layers, 80, seed=2)
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
+    m = make_model(sd, 24, 20, 5, n_layers, 80)
+    seeds = torch.arange(80 + 30, 80 + 150, device=DEV) if seeded else None
+    monkeypatch.setattr(ops, "TILED_MIN_WORK", 1)
+    outs = {}
+    for mode in ("never", "always"):
+        monkeypatch.setattr(ops, "WGNN_LINEAR", mode)
+        with torch.no_grad():
+            outs[mode] = m(g, dev(c["feats"]), seeds=seeds)
+            outs[mode + "16"] = m(g, dev(c["feats"]).half(), seeds=seeds)
+    rg = O.build_reference_graph(c["expr"], c["support_mask"])
+    ids = np.arange(80 + 30, 80 + 150) if seeded else np.arange(80, 80 + 150)
+    want = O.nodeflow_forward(sd, rg, torch.from_numpy(c["feats"]), ids, n_layers).numpy()
+    want16 = O.nodeflow_forward(sd, rg, torch.from_numpy(c["feats"]).half().float(), ids, n_layers).numpy()
+    for k in ("never", "always"):
+        np.testing.assert_allclose(outs[k].cpu().numpy(), want, atol=TOL, err_msg=k)
+        np.testing.assert_allclose(outs[k + "16"].cpu().numpy(), want16, atol=TOL, err_msg=k + "16")
+    assert (outs["never"] - outs["always"]).abs().max().item() < 2e-5
+    # training is untouched by the switch: gradients flow through the library GEMM + scale pass as before
+    monkeypatch.setattr(ops, "WGNN_LINEAR", "always")
+    m.train()
+    out = m(g, dev(c["feats"]), seeds=seeds)
+    out.sum().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+def test_int64_row_pointers_at_the_kernel_boundary():
+    """"rowptr[R+1] i32 or i64".  wgnn_normalize_rows_i64 and wgnn_agg_fwd / wgnn_agg_fwd_tiled with
+    WGNN_FLAG_ROWPTR_I64 (the kernels read rowptr for the inv_deg == NULL fallback) give the int32 results bit for bit."""
+    from scdeepsort_amd import _lib, ops
+    from scdeepsort_amd.graph import _ptr, _stream
+    c = small_case(cells=200, genes=90, dim=32, seed=23, test_cells=0)
+    g = sda.CellGeneGraph.from_expression(c["expr"], device=DEV, chunk=32)
+    d = torch.device(DEV)
+    csr = g.cg
+    x = sp.csr_matrix(c["expr"]).astype(np.float32); x.sort_indices()
+    rp64, raw = dev(x.indptr, torch.int64), dev(x.data)
+    v64, inv64 = torch.empty_like(raw), torch.empty(csr.n_rows, device=DEV)
+    assert _lib.call(d, "wgnn_normalize_rows_i64", _ptr(rp64), _ptr(raw), _ptr(v64), _ptr(inv64), csr.n_rows, _stream(d)) == 0
+    assert torch.equal(v64, csr.val) and torch.equal(inv64, csr.inv_deg)
+    alpha = torch.rand(92, device=DEV) + 0.5
+    hg, hc = dev(c["feats"][:90]), dev(c["feats"][90:])
+    want = sda.agg_fwd(csr, alpha, sda.SRC_IS_GENE, 91, hg, hc)
+    plan = csr.plan
+    part = torch.empty(max(1, plan.n_partials) * 32, device=DEV)
+
+    def run(rowptr, flags):
+        out = torch.empty(csr.n_rows, 32, device=DEV)
+        rc = _lib.call(d, "wgnn_agg_fwd", _ptr(rowptr), _ptr(csr.col), _ptr(csr.val), _ptr(alpha), sda.SRC_IS_GENE, 91,
+                       _ptr(hg), 32, _ptr(hc), 32, None, None, None, _ptr(out), 32, None, csr.n_rows, 32, 0, 0, flags,
+                       _ptr(plan.items), plan.n_items, _ptr(plan.long_rows) if plan.n_long else None, plan.n_long,
+                       _ptr(part), plan.n_partials, _stream(d))
+        assert rc == 0
+        return out
+    a32, a64 = run(csr.rowptr, 0), run(rp64, _lib.FLAG_ROWPTR_I64)          # inv_deg = NULL: 1/(deg+1) from rowptr
+    assert torch.equal(a32, a64) and torch.equal(a32, want)
+    tp = csr.tile_plan(ops.tiled_block_rows(32))
+    tpart = torch.empty(max(1, tp.n_partials) * 32, device=DEV)
+
+    def run_tiled(rowptr, flags):
+        out = torch.empty(csr.n_rows, 32, device=DEV); scratch = torch.empty_like(hg)
+        nl = tp.long_rows.shape[0]
+        rc = _lib.call(d, "wgnn_agg_fwd_tiled", _ptr(rowptr), _ptr(alpha), sda.SRC_IS_GENE, 91, _ptr(hg), 90, _ptr(scratch),
+                       _ptr(hc), 32, None, None, None, _ptr(out), 32, None, csr.n_rows, 32, flags,
+                       _ptr(tp.entries), _ptr(tp.seg_ptr), tp.nblk_max, tp.block_rows, _ptr(tp.items), _ptr(tp.hdr), tp.n_tiles,
+                       _ptr(tp.long_rows) if nl else None, nl, _ptr(tpart), tp.n_partials, _stream(d))
+        assert rc == 0
+        return out
+    t32, t64 = run_tiled(csr.rowptr, 0), run_tiled(rp64, _lib.FLAG_ROWPTR_I64)
+    assert torch.equal(t32, t64) and (t32 - want).abs().max().item() < 2e-5

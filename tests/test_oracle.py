@@ -271,3 +271,28 @@ def test_api_classify_matches_oracle_postprocess(unsure_rate):
     if unsure_rate == 3.0:
         assert (pred == -1).sum() > 100 and pred[0] == -1
     assert pred[2] in (0, -1) and (pred[2] == want[2])
+
+
+@pytest.mark.parametrize("blocked", [False, True])
+def test_c_port_matches_numpy_restatement(blocked):
+    """oracle/wgnn_oracle.c (the timed `cpu_baseline` of bench.py) - the row-wise port and its cache-blocked form (tile of
+    destination rows x block of source rows, ragged last tile / block, empty rows) - against the numpy CSR restatement, both
+    directions, and the whole forward in the project-first order."""
+    from oracle import c_oracle as CO
+    c = small_case(cells=130, genes=70, dim=24, hidden=16, n_classes=4, seed=9, test_cells=0)
+    G, C = c["G"], c["C"]
+    cg = O.build_csr_graph(c["expr"])
+    rng = np.random.default_rng(2)
+    alpha = (rng.random(G + 2) + 0.5).astype(np.float32)
+    Hg, Hc = c["feats"][:G], c["feats"][G:]
+    zc, zg = O.csr_aggregate(cg, alpha, Hg.astype(np.float64), Hc.astype(np.float64))
+    agg = (lambda *a: CO.aggregate_blocked(*a, tile_rows=32, block_rows=24)) if blocked else CO.aggregate
+    got_c = agg(cg.A_cg.indptr, cg.A_cg.indices, cg.A_cg.data, alpha, 0, G + 1, Hg, Hc)
+    got_g = agg(cg.A_gc.indptr, cg.A_gc.indices, cg.A_gc.data, alpha, 1, G, Hc, Hg)
+    np.testing.assert_allclose(got_c, zc, atol=2e-6)
+    np.testing.assert_allclose(got_g, zg, atol=2e-6)
+    sd = O.init_params(24, 16, 4, 2, G, seed=4)
+    want = O.csr_forward(sd, cg, c["feats"], 2)
+    got = CO.forward(sd, cg, c["feats"], 2, order="project_first_blocked" if blocked else "project_first")
+    np.testing.assert_allclose(got, want, atol=2e-5)
+    np.testing.assert_allclose(CO.forward(sd, cg, c["feats"], 2), want, atol=2e-5)       # the reference's aggregate-first order
