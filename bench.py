@@ -78,7 +78,7 @@ def cpu_baseline(graph, model, feats_g, feats_c, gpu_logits, cfg):
     t, reps, l3 = best_of(lambda: CO.forward(sd, ocg, feats, model.n_layers, order="project_first_blocked"), 5, 6.0)
     every.append({"name": "port_c_openmp_cache_blocked", "value": round(C / t, 1), "unit": "cells/s", "cores": CO.num_threads(),
                   "s_per_forward": round(t, 4), "sample": f"full {cfg.name} graph, best of {reps}; C/OpenMP aggregation tiled like the "
-                  "GPU kernel (256 destination rows x 256 source rows per step, accumulators and the source block L2-resident, "
+                  "GPU kernel (128-256 destination rows x 256 source rows per step, accumulators and the source block L2-resident, "
                   "AVX-512 body picked at load time) on the projected H-wide rows + torch Linear",
                   "max_abs_err_vs_gpu": float(np.abs(l3 - gpu).max())})
     t, reps, l2 = best_of(lambda: CB.b2_torch_csr_forward(sd, ocg, feats, model.n_layers), 3, 10.0)

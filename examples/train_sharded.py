@@ -44,15 +44,19 @@ def main():
     from scdeepsort_amd.sharded import ShardedWgnn
 
     cfg = S.CONFIGS[args.config]
-    lo, hi = shard_range(cfg.cells, rank, world)                      # the SAME job split over the ranks (strong scaling)
+    # BASELINE cfg4: "Same 100k x 20k graph ... cells sharded 8-way" - every rank generates the SAME graph from the reference
+    # seed (1.3 s at cfg3) and keeps its contiguous range of the cell axis, so an N-rank run trains on exactly the N = 1 job
+    lo, hi = shard_range(cfg.cells, rank, world)
     C, G = hi - lo, cfg.genes
-    rp, col, val = S.synth_expression(C, G, cfg.density, seed=S.REFERENCE_SEED + rank, device=dev)
+    rp, col, val = S.synth_expression(cfg.cells, G, cfg.density, seed=S.REFERENCE_SEED, device=dev)
+    b, e = int(rp[lo]), int(rp[hi])
+    rp, col, val = (rp[lo:hi + 1] - rp[lo]).clone(), col[b:e].clone(), val[b:e].clone()
     torch.manual_seed(1234)                                           # identical initial parameters on every rank
     model = sda.GNN(cfg.dense_dim, cfg.hidden, cfg.n_classes, cfg.n_layers, G, activation=F.relu, dropout=0.1).to(dev)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4)
     engine = ShardedWgnn.build(model, rp, col, val, G)
     feats_g = S.synth_features(G, cfg.dense_dim, seed=7, device=dev)
-    feats_c = S.synth_features(C, cfg.dense_dim, seed=100 + rank, device=dev)
+    feats_c = S.synth_features(cfg.cells, cfg.dense_dim, seed=100, device=dev)[lo:hi].clone()
     labels = (torch.arange(lo, hi, device=dev) * 2654435761 % cfg.n_classes).long()
     per_rank = args.batch_size // world if args.batch_size else 0
     gen = torch.Generator(device=dev).manual_seed(1 + rank)

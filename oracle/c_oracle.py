@@ -43,12 +43,14 @@ def aggregate(rowptr, col, val, alpha, mode, self_idx, h_src, h_self):
     return out
 
 
-def aggregate_blocked(rowptr, col, val, alpha, mode, self_idx, h_src, h_self, tile_rows=256, block_rows=256):
+def aggregate_blocked(rowptr, col, val, alpha, mode, self_idx, h_src, h_self, tile_rows=None, block_rows=256):
     """Cache-blocked form of :func:`aggregate` (tile of destination rows x block of source rows, see wgnn_oracle.c)."""
     rowptr = np.ascontiguousarray(rowptr, np.int32); col = np.ascontiguousarray(col, np.int32)
     val = np.ascontiguousarray(val, np.float32); alpha = np.ascontiguousarray(alpha, np.float32).ravel()
     h_src = np.ascontiguousarray(h_src, np.float32); h_self = np.ascontiguousarray(h_self, np.float32)
     R, D = h_self.shape
+    if tile_rows is None:          # measured on the GPU box's host (scratch/cpu_blocked_time.py): 128 for the many-row cell side
+        tile_rows = 128 if R >= 40_000 else 256
     out = np.empty((R, D), np.float32)
     pre = np.empty_like(h_src) if mode == 0 else h_src
     lib().oracle_aggregate_blocked(_p(rowptr), _p(col), _p(val), _p(alpha), C.c_int(mode), C.c_int32(self_idx),

@@ -43,8 +43,8 @@ struct LinArgs {
 // out2: a second, row-scaled copy of the result written from the same accumulators - the projected gene table P_g and
 // its alpha-folded form alpha[g] * P_g[g] (the source table of the LDS-streamed cells<-genes pass, models/gnn.py:54's
 // (h * alpha) factor) come out of ONE kernel instead of GEMM + scale_rows.
-template <typename TX>
-__global__ void __launch_bounds__(kLinThreads) linear_mfma_f32(const LinArgs a) {
+template <typename TX, bool DUAL>
+__global__ void __launch_bounds__(kLinThreads, 4) linear_mfma_f32(const LinArgs a) {
     __shared__ float As[2][kBM * kLd];
     __shared__ float Ws[2][kBN * kLd];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -125,8 +125,12 @@ __global__ void __launch_bounds__(kLinThreads) linear_mfma_f32(const LinArgs a) 
                 if (row < a.M) {
                     float v = acc[i][j][r] + bv;
                     if (relu) v = fmaxf(v, 0.f);
-                    if (a.out) a.out[row * a.ld_out + col] = v;
-                    if (a.out2) a.out2[row * a.ld_out2 + col] = a.row_scale[row] * v;
+                    if constexpr (DUAL) {
+                        if (a.out) a.out[row * a.ld_out + col] = v;
+                        a.out2[row * a.ld_out2 + col] = a.row_scale[row] * v;
+                    } else {
+                        a.out[row * a.ld_out + col] = v;
+                    }
                 }
             }
         }
@@ -279,8 +283,14 @@ extern "C" int wgnn_linear_fwd_ex(const void* x, int x_dtype, int64_t ld_x, cons
     if (tiles > 0x7FFFFFFFL) return WGNN_ERR_UNSUPPORTED;
     LinArgs a{x, (long)ld_x, w, (long)ld_w, bias, out, (long)ld_out, row_scale, out_scaled, (long)ld_out_scaled, (long)M, N, K, flags};
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (x_dtype == WGNN_F16) hipLaunchKernelGGL(linear_mfma_f32<__half>, dim3((unsigned)tiles), dim3(kLinThreads), 0, st, a);
-    else hipLaunchKernelGGL(linear_mfma_f32<float>, dim3((unsigned)tiles), dim3(kLinThreads), 0, st, a);
+    const dim3 grid((unsigned)tiles), block(kLinThreads);
+    if (x_dtype == WGNN_F16) {
+        if (out_scaled) hipLaunchKernelGGL((linear_mfma_f32<__half, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((linear_mfma_f32<__half, false>), grid, block, 0, st, a);
+    } else {
+        if (out_scaled) hipLaunchKernelGGL((linear_mfma_f32<float, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((linear_mfma_f32<float, false>), grid, block, 0, st, a);
+    }
     return hipGetLastError() == hipSuccess ? WGNN_OK : WGNN_ERR_LAUNCH;
 }
 

@@ -437,10 +437,14 @@ def weighted_sum(csr: AggCsr, h_src: torch.Tensor) -> torch.Tensor:
 # dense half of a layer through the C ABI (fp32 matrix cores) - see csrc/wgnn_linear.hip
 # ------------------------------------------------------------------------------------------------
 # GNN's projections on the no-grad path: which of them run through wgnn_linear_fwd_ex instead of the library GEMM
-#   "auto"  - fp16-stored inputs (never materialised in fp32), the gene table of a tile-kernel pass (P_g and alpha*P_g from one
-#             kernel, no scale_rows launch) and shapes where the kernel measured faster than hipBLASLt (>= 50k rows, K >= 384:
-#             95 vs 87 TF on 100k x 400 x 256, scratch/linear_time.py);   "always" / "never" - A/B switches
-WGNN_LINEAR = "auto"
+#   "auto"  - fp16-stored inputs (never materialised in fp32) and shapes where the kernel measured faster than hipBLASLt
+#             (>= 50k rows, K >= 384: 215 vs 231 us on 100k x 400 x 256, profiles/r03_kernel_stats_*.txt);
+#   "always" / "never" - A/B switches.
+# WGNN_LINEAR_DUAL: also produce the gene table P_g together with alpha * P_g (one kernel, no scale_rows launch).  Off by
+# default: on the 20k-row gene projections the 128 x 128-tile kernel runs 69 us against the library's 31 us + 8 us of
+# scale_rows (314 tiles = one thin round over 256 CUs), so the fusion costs more than it saves at cfg3.
+WGNN_LINEAR = __import__("os").environ.get("WGNN_LINEAR", "auto")
+WGNN_LINEAR_DUAL = __import__("os").environ.get("WGNN_LINEAR_DUAL", "0") == "1"
 WGNN_LINEAR_MIN_ROWS, WGNN_LINEAR_MIN_K = 50_000, 384
 
 
@@ -449,9 +453,11 @@ def use_wgnn_linear(x: torch.Tensor, weight: torch.Tensor, dual: bool = False) -
     if WGNN_LINEAR == "never" or not x.is_cuda or x.dim() != 2 or x.shape[1] % 4 or torch.is_grad_enabled() and (
             x.requires_grad or weight.requires_grad):
         return False
+    if dual:
+        return WGNN_LINEAR_DUAL
     if WGNN_LINEAR == "always":
         return True
-    return dual or x.dtype == torch.float16 or (x.shape[0] >= WGNN_LINEAR_MIN_ROWS and x.shape[1] >= WGNN_LINEAR_MIN_K)
+    return x.dtype == torch.float16 or (x.shape[0] >= WGNN_LINEAR_MIN_ROWS and x.shape[1] >= WGNN_LINEAR_MIN_K)
 
 
 def linear_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,

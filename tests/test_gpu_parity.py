@@ -1408,6 +1408,7 @@ def test_nograd_forward_through_wgnn_linear_and_prescaled_source(n_layers, seede
     outs = {}
     for mode in ("never", "always"):
         monkeypatch.setattr(ops, "WGNN_LINEAR", mode)
+        monkeypatch.setattr(ops, "WGNN_LINEAR_DUAL", mode == "always")
         with torch.no_grad():
             outs[mode] = m(g, dev(c["feats"]), seeds=seeds)
             outs[mode + "16"] = m(g, dev(c["feats"]).half(), seeds=seeds)
