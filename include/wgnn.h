@@ -293,7 +293,8 @@ int wgnn_linear_wgrad(const float* g, int64_t ld_g, const float* x, int64_t ld_x
                       int64_t M, int32_t N, int32_t K, int accumulate, float* workspace, int64_t n_slabs, void* stream);
 
 /* ---------------------------------------------------------------------------
- * One reference layer on a block in the reference's literal order (SURVEY 8b's optional fused entry):
+ * One reference layer on a block in the reference's literal order (SURVEY 8b's optional "fused variant" - here a COMPOSED
+ * entry: two launches through the caller's neigh_scratch, see DESIGN.md section 8 for why the fusion itself does not pay):
  *     neigh = nf.block_compute(i, message_func, fn.mean('m','neigh'))   (models/gnn.py:47-56,65)  = wgnn_agg_fwd (f32)
  *     out   = relu(fc_neigh(neigh))                                      (models/gnn.py:18-25)     = wgnn_linear_fwd
  * Arguments up to n_partials as wgnn_agg_fwd (f32 in/out, no bias, agg_flags without WGNN_FLAG_RELU);

@@ -293,7 +293,7 @@ def _predict(species, tissue, input_file, model_path: Path, save_path, unsure_ra
     model = GNN(dense_dim, hidden_dim, len(id2label), n_layers, G, activation=F.relu, dropout=0.1).to(dev)
     model.load_state_dict(state)
     model.eval()
-    seeds = torch.arange(G + n_sup, G + expr.shape[0], device=dev)
+    seeds = range(G + n_sup, G + expr.shape[0])           # the test cells: one contiguous block of node ids (predict.py:64-76)
     with torch.no_grad():
         pred, _ = _classify(model(graph, feats, seeds=seeds), unsure_rate)
     names = [id2label[p] if p >= 0 else "unsure" for p in pred]

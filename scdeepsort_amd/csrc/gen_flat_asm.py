@@ -51,6 +51,7 @@ def wreg(p):
     return WREGS[p % (DEPTH + 1)]
 
 
+FMA2 = "fma2" in ABLATE          # v_fma_f32 x4 instead of v_pk_fma_f32 x2 per entry (a REAL variant: results stay correct)
 WRL = "wrl" in ABLATE            # experiment: weights through v_readlane into SGPR pairs instead of the LDS strip
 SCR = 92                         # scratch SGPR of the computed branch
 ORDER = os.environ.get("WGNN_GEN_ORDER", "RLAWF")     # order of a step's groups: R(eads) L(readlanes) W(ait) F(mas) A(ddresses)
@@ -101,6 +102,13 @@ def fmas(p):
         return []
     w = f"v[{wreg(p)}:{wreg(p) + 1}]"
     lo, hi = "op_sel_hi:[0,1,1]", "op_sel:[1,0,0] op_sel_hi:[1,1,1]"
+    if FMA2:       # experiment: four v_fma_f32 per entry instead of two v_pk_fma_f32 (same arithmetic, same registers)
+        w0, w1 = wreg(p), wreg(p) + 1
+        return [f"s_set_gpr_idx_on s{s['pk0']}, gpr_idx(SRC2,DST)"] + \
+               [f"v_fma_f32 v{64 + k}, v{w0}, v{x0 + k}, v{64 + k}" for k in range(4)] + \
+               [f"s_set_gpr_idx_idx s{s['pk1']}"] + \
+               [f"v_fma_f32 v{64 + k}, v{w1}, v{x1 + k}, v{64 + k}" for k in range(4)] + \
+               ["s_set_gpr_idx_off"]
     if WRL:
         w0, w1 = wsgpr(p)
         return [f"s_set_gpr_idx_on s{s['pk0']}, gpr_idx(SRC2,DST)",

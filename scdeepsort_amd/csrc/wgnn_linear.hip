@@ -4,7 +4,7 @@
 //                                          classifier head    = linear(h)               (reference models/gnn.py:66-67)
 //
 // Why it exists: (1) the C ABI (include/wgnn.h) is otherwise not self-sufficient for one whole layer - a non-torch
-// caller would have to bring its own GEMM; (2) SURVEY 8b lists the fused `wgnn_agg_linear_relu_fwd`; (3) north_star
+// caller would have to bring its own GEMM; (2) SURVEY 8b lists `wgnn_agg_linear_relu_fwd` (composed here: aggregation launch + this GEMM); (3) north_star
 // allows MFMA where the dense feature x weight projection matters: at BASELINE cfg3 the projections are 40 GFLOP =
 // ~11 % of a forward.  v_mfma_f32_32x32x2_f32 is EXACT fp32 (bitwise an fmaf chain in k order, MI355X_MICROARCH.md) at
 // the fp32 vector rate (157 TF chip peak), so parity with the oracle's fp32 Linear needs no tolerance beyond summation

@@ -171,6 +171,18 @@ class GNN(nn.Module):
                 raise ValueError(f"features must have {g.num_nodes} rows (genes then cells, preprocess_internal.py:202)")
             h_g, h_c = features[:G], features[G:]
         cell_rows = None
+        if isinstance(seeds, range):
+            # a contiguous block of cells (predict.py:61-88: the test cells of a predict graph are nodes G+n_support .. N-1).
+            # When it is a sizeable share of a tile-kernel operand the cheapest evaluation is the plain full pass, sliced:
+            # no seed gather / scatter at all (the support cells' rows are computed alongside and dropped).
+            if seeds.step != 1 or seeds.start < G or seeds.stop > G + g.num_cells:
+                raise ValueError("a seed range must be a step-1 range of cell node ids")
+            H0 = self.layers[0].fc_neigh.weight.shape[0]
+            big = (_ops.TILED_MIN_WORK is not None and g.cg.nnz * min(H0, 256) >= _ops.TILED_MIN_WORK
+                   and len(seeds) >= _ops.SEED_FULL_PASS_MIN_FRAC * g.num_cells)
+            if big:
+                return self.embed(g, features, None)[seeds.start - G: seeds.stop - G]
+            seeds = torch.arange(seeds.start, seeds.stop, device=g.device)
         if seeds is not None:
             cell_rows = (seeds.to(g.device) - G).to(torch.int32)
         # Which cell rows a layer must produce: cells are never sources for cells, so below the last layer a cell's
@@ -236,6 +248,7 @@ class GNN(nn.Module):
                 seeds: Optional[torch.Tensor] = None, num_neighbors: int = 0,
                 generator: Optional[torch.Generator] = None, nodeflow=None) -> torch.Tensor:
         """Logits ``[len(seeds), n_classes]`` (all cells in order when ``seeds`` is None); no softmax (gnn.py:66-68).
+        ``seeds``: node ids (>= G) as a tensor in any order, or a Python ``range`` for a contiguous block of cells.
 
         ``num_neighbors > 0`` draws a NodeFlow with at most that many in-edges per node (train.py:37-40); ``generator`` is
         a ``sampler.DeviceSampler`` (K5 ``wgnn_sample_rows``: static shapes, sync-free, hipGraph-capturable) or a
@@ -247,6 +260,8 @@ class GNN(nn.Module):
                 raise ValueError("pass features or set graph.features")
         if nodeflow is None and num_neighbors:
             from .sampler import DeviceSampler, sample_nodeflow, sample_nodeflow_static
+            if isinstance(seeds, range):
+                seeds = torch.arange(seeds.start, seeds.stop, seeds.step, device=g.device)
             cells = (seeds.to(g.device) - self.gene_num) if seeds is not None \
                 else torch.arange(g.num_cells, device=g.device)
             if isinstance(generator, DeviceSampler):        # K5: static shapes, no host synchronisation, capturable

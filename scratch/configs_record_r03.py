@@ -34,7 +34,8 @@ rp, col, val = S.synth_expression(n_sup + n_test, G, 0.04, device=dev)
 mask = torch.zeros(n_sup + n_test, dtype=torch.bool, device=dev); mask[:n_sup] = True
 g = sda.CellGeneGraph.from_device_csr(rp, col, val, G, support_mask=mask)
 feats = S.synth_features(G + n_sup + n_test, 400, device=dev)
-seeds = torch.arange(G + n_sup, G + n_sup + n_test, device=dev)
+seeds = range(G + n_sup, G + n_sup + n_test)            # what api._predict passes (contiguous block of test cells)
+seeds_t = torch.arange(G + n_sup, G + n_sup + n_test, device=dev)
 def timed(fn, reps=10):
     for _ in range(3): o = fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -54,10 +55,12 @@ for L in (1, 2):
         a, t_seed = timed(lambda: m(g, feats, seeds=seeds))
         b, t_all = timed(lambda: m(g, feats))
         old, ops.SEED_FULL_PASS_MIN_FRAC = ops.SEED_FULL_PASS_MIN_FRAC, 2.0          # round-2 behaviour: every seed call on the row-wave kernel
-        c, t_k1 = timed(lambda: m(g, feats, seeds=seeds), reps=3)
+        c, t_k1 = timed(lambda: m(g, feats, seeds=seeds_t), reps=3)
         ops.SEED_FULL_PASS_MIN_FRAC = old
+        perm = seeds_t[torch.randperm(n_test, device=dev)]
+        d, t_perm = timed(lambda: m(g, feats, seeds=perm))
     pred[f"{L}_layer"] = {"ms_seeds_eq_test_cells": round(t_seed, 3), "ms_seeds_none_all_cells": round(t_all, 3),
-                          "ms_round2_rowwave_route": round(t_k1, 3), "test_cells_per_s": round(n_test / t_seed * 1e3, 1),
+                          "ms_round2_rowwave_route": round(t_k1, 3), "ms_seeds_eq_test_cells_shuffled_tensor": round(t_perm, 3), "test_cells_per_s": round(n_test / t_seed * 1e3, 1),
                           "kernels_of_the_seed_call": kern, "max_abs_vs_all_cells_pass": float((a - b[n_sup:]).abs().max()),
                           "max_abs_vs_rowwave_route": float((a - c).abs().max())}
 out["predictor_shaped_inference"] = {"graph": f"{n_sup} support + {n_test} test cells x {G} genes, nnz {g.cg.nnz}, dense_dim 400, hidden 200",

@@ -1472,3 +1472,28 @@ def test_int64_row_pointers_at_the_kernel_boundary():
         return out
     t32, t64 = run_tiled(csr.rowptr, 0), run_tiled(rp64, _lib.FLAG_ROWPTR_I64)
     assert torch.equal(t32, t64) and (t32 - want).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("n_layers", [1, 2])
+def test_range_seeds_are_the_contiguous_test_cells_of_a_predict_graph(n_layers, monkeypatch):
+    """`seeds=range(G + n_support, N)` (what api._predict passes, predict.py:64-76) == the same ids as a tensor == the
+    oracle's NodeFlow on those seeds; on a tile-kernel operand the range takes the full pass + slice, below it the
+    row-wave seed path."""
+    from scdeepsort_amd import ops
+    c = small_case(cells=140, genes=60, dim=20, hidden=12, n_classes=4, seed=51, test_cells=100)
+    sd = O.init_params(20, 12, 4, n_layers, 60, seed=6)
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
+    m = make_model(sd, 20, 12, 4, n_layers, 60)
+    rng_ids = range(60 + 40, 60 + 140)
+    rg = O.build_reference_graph(c["expr"], c["support_mask"])
+    want = O.nodeflow_forward(sd, rg, torch.from_numpy(c["feats"]), np.arange(100, 200), n_layers).numpy()
+    x = dev(c["feats"])
+    with torch.no_grad():
+        small = m(g, x, seeds=rng_ids)                                   # below TILED_MIN_WORK: row-wave seed path
+        monkeypatch.setattr(ops, "TILED_MIN_WORK", 1)
+        big = m(g, x, seeds=rng_ids)                                     # full LDS-streamed pass, sliced
+        as_tensor = m(g, x, seeds=torch.arange(100, 200, device=DEV))
+    for got in (small, big, as_tensor):
+        np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL)
+    with pytest.raises(ValueError):
+        m(g, x, seeds=range(10, 70))                                     # gene ids are not seeds
