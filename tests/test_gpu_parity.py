@@ -1497,3 +1497,27 @@ def test_range_seeds_are_the_contiguous_test_cells_of_a_predict_graph(n_layers, 
         np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL)
     with pytest.raises(ValueError):
         m(g, x, seeds=range(10, 70))                                     # gene ids are not seeds
+
+
+def test_subplan_with_pathologically_long_rows():
+    """a row that needs more than 64 chunks of the plan's chunk length is cut into 64 EQUAL parts by the
+    device-built seed plan (graph.AggCsr.subplan) - a different summation order than the full-graph plan, so the seed row
+    equals its full-pass row to rounding (not bitwise), deterministically and independently of the batch it arrives in."""
+    rng = np.random.default_rng(5)
+    C, G, D = 40, 2000, 32
+    dense = (rng.random((C, G)) < 0.02) * rng.uniform(0.5, 7.0, (C, G))
+    dense[7, :1500] = rng.uniform(0.5, 7.0, 1500)                           # a cell expressing 1500 genes: 94 chunks of 16
+    expr = sp.csr_matrix(dense.astype(np.float32))
+    g = sda.CellGeneGraph.from_expression(expr, device=DEV, chunk=16)
+    assert g.cg.max_row_nnz > 64 * g.cg.plan.chunk
+    alpha = torch.rand(G + 2, device=DEV) + 0.5
+    hg, hc = dev(rng.standard_normal((G, D))), dev(rng.standard_normal((C, D)))
+    full = sda.agg_fwd(g.cg, alpha, sda.SRC_IS_GENE, G + 1, hg, hc)
+    ids = torch.tensor([7, 3, 7, 20], device=DEV)
+    a = sda.agg_fwd(g.cg, alpha, sda.SRC_IS_GENE, G + 1, hg, hc, row_ids=ids)
+    b = sda.agg_fwd(g.cg, alpha, sda.SRC_IS_GENE, G + 1, hg, hc, row_ids=torch.tensor([20, 7], device=DEV))
+    assert (a - full[ids]).abs().max().item() < 2e-5
+    assert torch.equal(a[0], a[2]) and torch.equal(a[0], b[1]) and torch.equal(a[3], b[0])     # batch-independent
+    cgo = O.build_csr_graph(expr)
+    zc, _ = O.csr_aggregate(cgo, alpha.cpu().numpy(), hg.cpu().numpy().astype(np.float64), hc.cpu().numpy().astype(np.float64), want_genes=False)
+    np.testing.assert_allclose(a.cpu().numpy(), zc[[7, 3, 7, 20]], atol=TOL)
