@@ -50,6 +50,9 @@ struct TArgs {
     const int2* tile_hdr;     // [n_tiles] {col_begin, col_end}
     int nblk_max;
     int kb;                   // source rows per LDS block
+    int n_loaders;            // flat kernel: 0 = every wave streams its share of the source rows; L > 0 = waves 0..L-1 own no
+                              // destination rows (the plan deals them none) and issue the WHOLE global->LDS stream of the
+                              // steady-state blocks, the other 16 - L waves only compute
 };
 
 // out[r] = scale[r] * in[r]   (alpha folded into the source table; tiny: |table| bytes)
@@ -253,20 +256,20 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
             return;
         }
         // EXEC is narrowed to the D/4 lanes that carry data for the duration of the burst (a D < 256 row is shorter than
-        // its 1 KiB LDS slot; the slot's tail is never read by a lane that is stored)
-#define WGNN_FILL_NEXT(K)                                                                                   \
-        "s_cmp_lt_u32 %[np], " #K "\n\ts_cbranch_scc1 .Lw4_fd_%=\n\t"                                        \
-        "s_add_u32 m0, m0, %[ms]\n\ts_add_u32 s94, s94, s90\n\ts_addc_u32 s95, s95, 0\n\t"               \
-        "global_load_lds_dwordx4 %[vo], s[94:95]\n\t"
+        // its 1 KiB LDS slot; the slot's tail is never read by a lane that is stored).  One piece per loop trip: M0 / the
+        // 64-bit source address advance by nw rows.
+        int left = np;                                        // pieces still to issue (>= 1)
         asm volatile("s_mov_b64 s[92:93], exec\n\ts_sub_u32 s91, 64, %[n4]\n\ts_mul_i32 s90, %[n4], %[gs]\n\t"   // s90 = nw rows x D*4 B
                      "s_lshr_b64 exec, s[92:93], s91\n\t"                                                       // lanes 0 .. D/4-1
                      "s_mov_b64 s[94:95], %[g]\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\t"
+                     ".Lw4_fl_%=:\n\t"
                      "global_load_lds_dwordx4 %[vo], s[94:95]\n\t"
-                     WGNN_FILL_NEXT(2) WGNN_FILL_NEXT(3) WGNN_FILL_NEXT(4) WGNN_FILL_NEXT(5)
-                     ".Lw4_fd_%=:\n\ts_mov_b64 exec, s[92:93]"
-                     ::[g] "s"(g), [l] "s"(l), [vo] "v"(lane16), [np] "s"(np), [n4] "s"(n4), [ms] "s"(nw * row_bytes), [gs] "s"(nw * 16)
+                     "s_add_u32 m0, m0, %[ms]\n\ts_add_u32 s94, s94, s90\n\ts_addc_u32 s95, s95, 0\n\t"
+                     "s_sub_u32 %[left], %[left], 1\n\ts_cmp_lg_u32 %[left], 0\n\ts_cbranch_scc1 .Lw4_fl_%=\n\t"
+                     "s_mov_b64 exec, s[92:93]"
+                     : [left] "+s"(left)
+                     : [g] "s"(g), [l] "s"(l), [vo] "v"(lane16), [n4] "s"(n4), [ms] "s"(nw * row_bytes), [gs] "s"(nw * 16)
                      : "m0", "memory", "scc", "s90", "s91", "s92", "s93", "s94", "s95");
-#undef WGNN_FILL_NEXT
     };
     auto fill = [&](int b) { fill_rows(cb + b * kKB, min(kKB, ce - (cb + b * kKB)), b & 1, kTW); };
     // RIGHT-aligned entry chunk of segment [s, e): with n = min(64, e - s) entries, lane j <- entry s + j - (64 - n);
@@ -325,6 +328,7 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
     };
     // Steady state (b + 3 < nblk, so blocks b+1, b+2, b+3 exist and block b+1 is a full one): no range checks, the
     // segment pointer / DMA source row / buffer parity advance incrementally.
+    const int nld = t.n_loaders;                             // dedicated loader waves (0 = none)
     const int* segp = seg + 3 * kTW;                         // -> segment of block b+3
     int fill_row = cb + kKB;                                 // first source row of block b+1
     auto fast_block = [&](auto cur_set, auto nxt_set, int par, int cs, int ce0, int& ns, int& ne) {
@@ -333,7 +337,7 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
         asm volatile("v_readfirstlane_b32 %0, v32\n\tv_readfirstlane_b32 %1, v33" : "=s"(ns), "=s"(ne)::"memory");
         seg_load(segp);
         segp += kTW;
-        if (do_fill) fill_rows(fill_row, kKB, par ^ 1, kTW);
+        if (do_fill && (nld == 0 || wave < nld)) fill_rows(fill_row, kKB, par ^ 1, nld ? nld : kTW);
         fill_row += kKB;
         chunk_issue(nxt_set, ns, ne);
         if (do_comp) compute(cur_set, cs, ce0, (int)(size_t)smem + par * buf_bytes);
@@ -467,7 +471,8 @@ extern "C" int wgnn_agg_fwd_tiled(const void* rowptr, const float* alpha, int al
     if (neigh_sum && !aligned16(neigh_sum)) return WGNN_ERR_ALIGNMENT;
     a.long_rows = reinterpret_cast<const int4*>(long_rows); a.n_long = n_long; a.partials = partials;
     TArgs t{reinterpret_cast<const int2*>(entries), seg_ptr, reinterpret_cast<const int4*>(tile_items),
-            reinterpret_cast<const int2*>(tile_hdr), nblk_max, block_rows};
+            reinterpret_cast<const int2*>(tile_hdr), nblk_max, block_rows, (int)((flags >> 8) & 0xF)};
+    if (t.n_loaders >= kTW) return WGNN_ERR_BAD_ARG;
     int rc = launch_tiled<float, EPI_FWD>(a, t, n_tiles, st);
     if (rc) return rc;
     if (n_long > 0) return launch_finalize_f32(a, EPI_FWD, st);
@@ -512,7 +517,7 @@ extern "C" int wgnn_agg_bwd_src_tiled(const float* alpha, int alpha_mode, const 
     a.D = D; a.flags = WGNN_FLAG_NO_MEAN; a.accumulate = accumulate;
     a.long_rows = reinterpret_cast<const int4*>(long_rows); a.n_long = n_long; a.partials = partials;
     TArgs t{reinterpret_cast<const int2*>(entries), seg_ptr, reinterpret_cast<const int4*>(tile_items),
-            reinterpret_cast<const int2*>(tile_hdr), nblk_max, block_rows};
+            reinterpret_cast<const int2*>(tile_hdr), nblk_max, block_rows, 0};
     rc = launch_tiled<float, EPI_BWD_SRC>(a, t, n_tiles, st);
     if (rc) return rc;
     if (n_long > 0) return launch_finalize_f32(a, EPI_BWD_SRC, st);
@@ -539,7 +544,7 @@ extern "C" int wgnn_agg_bwd_alpha_tiled(const float* inv_deg, const float* g, in
     a.D = D; a.flags = 0;
     a.long_rows = reinterpret_cast<const int4*>(long_rows); a.n_long = n_long; a.partials = partials;
     TArgs t{reinterpret_cast<const int2*>(entries), seg_ptr, reinterpret_cast<const int4*>(tile_items),
-            reinterpret_cast<const int2*>(tile_hdr), nblk_max, block_rows};
+            reinterpret_cast<const int2*>(tile_hdr), nblk_max, block_rows, 0};
     hipStream_t st = static_cast<hipStream_t>(stream);
     rc = launch_tiled<float, EPI_BWD_ALPHA>(a, t, n_tiles, st);
     if (rc) return rc;

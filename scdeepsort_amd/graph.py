@@ -193,14 +193,16 @@ class AggCsr:
             self._t._max_row_nnz = self.n_rows if host is None else None
         return self._t
 
-    def tile_plan(self, block_rows: int = 64):
+    def tile_plan(self, block_rows: int = 64, loaders: Optional[int] = None):
         """Lazily built plan for the LDS-streamed kernel (heuristic tile geometry, see build_tile_plan), cached per
-        LDS block height."""
+        LDS block height and number of dedicated loader waves (``loaders=None``: the module default; the backward entries
+        pass 0)."""
         if self._tile_plan is None:
             self._tile_plan = {}
-        if block_rows not in self._tile_plan:
-            self._tile_plan[block_rows] = build_tile_plan(self, None, None, block_rows=block_rows)
-        return self._tile_plan[block_rows]
+        key = (block_rows, TILE_LOADER_WAVES if loaders is None else loaders)
+        if key not in self._tile_plan:
+            self._tile_plan[key] = build_tile_plan(self, None, None, block_rows=block_rows, n_loaders=key[1])
+        return self._tile_plan[key]
 
     @property
     def max_row_nnz(self) -> int:
@@ -401,6 +403,10 @@ class CellGeneGraph:
 # ------------------------------------------------------------------------------------------------
 TILE_ROWS = 256          # 16 waves x 16 rows (kTW x kRPW in csrc/wgnn_tiled.hip)
 TILE_WAVES = 16
+# Dedicated loader waves of the flat tile kernel: the first L waves of a tile own no destination rows and issue the whole
+# global->LDS stream of the steady-state blocks; the other 16 - L waves only compute.  Used when a tile's rows fit the
+# remaining 16 x (16 - L) accumulator slots (cfg3's cell side: 195 rows per tile = 13 waves x 15 rows).  0 = off.
+TILE_LOADER_WAVES = 0
 
 
 @dataclass
@@ -411,6 +417,7 @@ class TilePlan:
     n_partials: int
     n_row_tiles: int
     n_col_splits: int
+    n_loaders: int = 0                         # waves 0..n_loaders-1 of every tile own no rows (dedicated loader waves)
     entries: Optional[torch.Tensor] = None     # int32 [nnz, 2]  {dst_slot<<8 | src_local, weight bits}
     seg_ptr: Optional[torch.Tensor] = None     # int32 [n_tiles*nblk_max*16 + 1]
     nblk_max: int = 0
@@ -476,7 +483,7 @@ def _flat_tile_index(n_col_splits: int, n_row_tiles: int, dev) -> torch.Tensor:
 
 
 def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits: Optional[int] = 1,
-                    n_cus: int = 256, block_rows: int = 64, balance: bool = True) -> TilePlan:
+                    n_cus: int = 256, block_rows: int = 64, balance: bool = True, n_loaders: int = 0) -> TilePlan:
     """Group the rows of ``csr`` into tiles of <= 256 rows (nnz-balanced across tiles and across the 16
     waves of a tile) and optionally split the column (source) range so hub rows spread over several
     workgroups.  Pure index arithmetic on the device; runs once per graph.
@@ -518,6 +525,14 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
         raise ValueError("tile overflow")
     wave = _snake(rnd, TILE_WAVES)
     slot_in_wave = rnd // TILE_WAVES
+    n_loaders = int(n_loaders or 0)
+    rows_per_tile = -(-V // n_row_tiles) if V else 0
+    if n_loaders and rows_per_tile <= (TILE_ROWS // TILE_WAVES) * (TILE_WAVES - n_loaders):
+        cw = TILE_WAVES - n_loaders                                         # computing waves: rows dealt in snake order over them
+        wave = n_loaders + _snake(rnd, cw)
+        slot_in_wave = rnd // cw
+    else:
+        n_loaders = 0                                                        # does not fit: every wave computes and streams
     local = wave * (TILE_ROWS // TILE_WAVES) + slot_in_wave
     # column splits on block boundaries
     blk = block_rows
@@ -574,4 +589,4 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
     entries = torch.stack([meta[perm], csr.val.view(torch.int32)[perm]], 1).contiguous()
     del perm, meta
     return TilePlan(items.contiguous(), hdr.contiguous(), long_rows, n_part,
-                    n_row_tiles, n_col_splits, entries, seg_ptr.to(torch.int32), nblk_max, block_rows)
+                    n_row_tiles, n_col_splits, n_loaders, entries, seg_ptr.to(torch.int32), nblk_max, block_rows)

@@ -30,6 +30,7 @@ def _worker(rank, world, port, out_dir, cells=90):
     from scdeepsort_amd import dist as D
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    D.FORCE_COLLECTIVES = world == 1          # a one-rank group still issues every collective (the GPU suite does this with nccl)
     try:
         c = small_case(cells=cells, genes=40, dim=12, hidden=8, n_classes=3, seed=21, test_cells=0)
         G, C = c["G"], c["C"]
@@ -127,7 +128,7 @@ def _worker(rank, world, port, out_dir, cells=90):
         x = torch.arange(10, dtype=torch.float64).reshape(2, 5)
         (p * x[rank]).sum().backward()
         D.all_reduce_grads([p])
-        np.testing.assert_allclose(p.grad.numpy(), x.sum(0).numpy())
+        np.testing.assert_allclose(p.grad.numpy(), x[:world].sum(0).numpy())
         Path(out_dir, f"ok{rank}").write_text("ok")
     finally:
         dist.destroy_process_group()
@@ -138,6 +139,13 @@ def test_world2_sharded_forward_matches_unsharded(tmp_path, cells):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), cells), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_one_rank_group_with_forced_collectives(tmp_path):
+    """`dist.FORCE_COLLECTIVES`: a ONE-rank communicator runs the whole sharded orchestration incl. every collective (how the
+    GPU suite exercises RCCL on a 1-GPU box); same checks as the world-2 run."""
+    mp.spawn(_worker, args=(1, _free_port(), str(tmp_path), 90), nprocs=1, join=True)
+    assert (tmp_path / "ok0").exists()
 
 
 def test_shard_ranges_partition_cells():
