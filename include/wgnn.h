@@ -152,7 +152,11 @@ int wgnn_agg_fwd(const void* rowptr /* int32_t[R+1]; int64_t[R+1] with WGNN_FLAG
  *     `block_rows` rows.  The tile plan is a re-ordering of the CSR (built once per graph):
  *
  *   tile_hdr   : int32[n_tiles * 2]        {col_begin, col_end} = source range the tile reduces over
- *   tile_items : int32[n_tiles * 256 * 4]  per tile, wave-major: {row_slot | -1 (padding), -, -, partial_slot | -1}
+ *   tile_items : int32[n_tiles * 256 * 4]  per tile, wave-major: {row_slot | -1 (padding), -, -, partial_slot | -1};
+ *                                          a wave's 16 slots are filled from slot 0.  LOADER WAVES: the leading waves of a tile
+ *                                          whose slot 0 is empty own no rows - the kernel makes them issue the tile's whole
+ *                                          global->LDS stream while the other waves only compute (a plan that gives every
+ *                                          wave rows keeps all 16 waves streaming their share; same results either way)
  *   entries    : int32[nnz * 2]            {dst_slot_in_wave << 8 | src_row_in_block, weight (f32 bits)}
  *                                          sorted by (tile, block, wave, dst_slot); block = (col-col_begin)/64
  *   seg_ptr    : int32[n_tiles*nblk_max*16 + 1]  entry offsets per (tile, block, wave)

@@ -50,9 +50,6 @@ struct TArgs {
     const int2* tile_hdr;     // [n_tiles] {col_begin, col_end}
     int nblk_max;
     int kb;                   // source rows per LDS block
-    int n_loaders;            // flat kernel: 0 = every wave streams its share of the source rows; L > 0 = waves 0..L-1 own no
-                              // destination rows (the plan deals them none) and issue the WHOLE global->LDS stream of the
-                              // steady-state blocks, the other 16 - L waves only compute
 };
 
 // out[r] = scale[r] * in[r]   (alpha folded into the source table; tiny: |table| bytes)
@@ -328,7 +325,20 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
     };
     // Steady state (b + 3 < nblk, so blocks b+1, b+2, b+3 exist and block b+1 is a full one): no range checks, the
     // segment pointer / DMA source row / buffer parity advance incrementally.
-    const int nld = t.n_loaders;                             // dedicated loader waves (0 = none)
+    // Dedicated loader waves (round 3).  A property of the PLAN: the leading waves of a tile that own no destination rows
+    // (graph.build_tile_plan(n_loaders=L) deals them none; a wave's row slots fill from slot 0, so "slot 0 empty" = "no
+    // rows") issue the tile's WHOLE global->LDS stream in the steady-state blocks, the other waves only compute.  When
+    // every wave owns rows (nld == 0) or the tile is empty (nld == 16) all 16 waves stream their share as before.
+    int nld = 0;
+    {
+        cptr_t slot0 = (cptr_t)(t.tile_items + (size_t)tile * kTileRows);        // int4 items: .x of item i at dword 4*i
+        bool leading = true;
+        for (int w = 0; w < kTW; ++w) {
+            const int x = slot0[w * kRPW * 4];
+            leading = leading && x < 0;
+            nld += leading ? 1 : 0;
+        }
+    }
     const int* segp = seg + 3 * kTW;                         // -> segment of block b+3
     int fill_row = cb + kKB;                                 // first source row of block b+1
     auto fast_block = [&](auto cur_set, auto nxt_set, int par, int cs, int ce0, int& ns, int& ne) {
@@ -471,8 +481,7 @@ extern "C" int wgnn_agg_fwd_tiled(const void* rowptr, const float* alpha, int al
     if (neigh_sum && !aligned16(neigh_sum)) return WGNN_ERR_ALIGNMENT;
     a.long_rows = reinterpret_cast<const int4*>(long_rows); a.n_long = n_long; a.partials = partials;
     TArgs t{reinterpret_cast<const int2*>(entries), seg_ptr, reinterpret_cast<const int4*>(tile_items),
-            reinterpret_cast<const int2*>(tile_hdr), nblk_max, block_rows, (int)((flags >> 8) & 0xF)};
-    if (t.n_loaders >= kTW) return WGNN_ERR_BAD_ARG;
+            reinterpret_cast<const int2*>(tile_hdr), nblk_max, block_rows};
     int rc = launch_tiled<float, EPI_FWD>(a, t, n_tiles, st);
     if (rc) return rc;
     if (n_long > 0) return launch_finalize_f32(a, EPI_FWD, st);
@@ -517,7 +526,7 @@ extern "C" int wgnn_agg_bwd_src_tiled(const float* alpha, int alpha_mode, const 
     a.D = D; a.flags = WGNN_FLAG_NO_MEAN; a.accumulate = accumulate;
     a.long_rows = reinterpret_cast<const int4*>(long_rows); a.n_long = n_long; a.partials = partials;
     TArgs t{reinterpret_cast<const int2*>(entries), seg_ptr, reinterpret_cast<const int4*>(tile_items),
-            reinterpret_cast<const int2*>(tile_hdr), nblk_max, block_rows, 0};
+            reinterpret_cast<const int2*>(tile_hdr), nblk_max, block_rows};
     rc = launch_tiled<float, EPI_BWD_SRC>(a, t, n_tiles, st);
     if (rc) return rc;
     if (n_long > 0) return launch_finalize_f32(a, EPI_BWD_SRC, st);
@@ -544,7 +553,7 @@ extern "C" int wgnn_agg_bwd_alpha_tiled(const float* inv_deg, const float* g, in
     a.D = D; a.flags = 0;
     a.long_rows = reinterpret_cast<const int4*>(long_rows); a.n_long = n_long; a.partials = partials;
     TArgs t{reinterpret_cast<const int2*>(entries), seg_ptr, reinterpret_cast<const int4*>(tile_items),
-            reinterpret_cast<const int2*>(tile_hdr), nblk_max, block_rows, 0};
+            reinterpret_cast<const int2*>(tile_hdr), nblk_max, block_rows};
     hipStream_t st = static_cast<hipStream_t>(stream);
     rc = launch_tiled<float, EPI_BWD_ALPHA>(a, t, n_tiles, st);
     if (rc) return rc;

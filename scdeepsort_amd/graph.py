@@ -403,10 +403,13 @@ class CellGeneGraph:
 # ------------------------------------------------------------------------------------------------
 TILE_ROWS = 256          # 16 waves x 16 rows (kTW x kRPW in csrc/wgnn_tiled.hip)
 TILE_WAVES = 16
-# Dedicated loader waves of the flat tile kernel: the first L waves of a tile own no destination rows and issue the whole
-# global->LDS stream of the steady-state blocks; the other 16 - L waves only compute.  Used when a tile's rows fit the
-# remaining 16 x (16 - L) accumulator slots (cfg3's cell side: 195 rows per tile = 13 waves x 15 rows).  0 = off.
-TILE_LOADER_WAVES = 0
+# Dedicated loader waves of the flat tile kernel (round 3): the first L waves of a tile own no destination rows and issue the
+# whole global->LDS stream of the steady-state blocks; the other 16 - L waves only compute.  Used when a tile's rows fit the
+# remaining 16 x (16 - L) accumulator slots (cfg3's cell side: 195 rows per tile = 14 waves x 14 rows; the gene side's
+# 243-row tiles do not fit and keep 16 symmetric waves).  Same results bit for bit; cfg3 cells<-genes 1.28 -> 1.20 ms on one
+# box, 1.29 -> 1.15 on another (L = 1 is bound by the single loader at 1.33 ms, L = 3 by the 13 computing waves at 1.17-1.23).
+# 0 = off.
+TILE_LOADER_WAVES = 2
 
 
 @dataclass
@@ -437,13 +440,17 @@ def _snake(p: torch.Tensor, n: int) -> torch.Tensor:
 ONE_ROUND_MIN_NNZ = 0               # one round wins or ties at every size measured: 2.0 M edges 62 vs 75 us, 11.9 M even, 39.8 M -20 %, 79.8 M -14 %, 159.8 M -13 % (scratch/geom_rounds.py, cfg2_crossover.py)
 
 
-def auto_tile_geometry(n_rows: int, n_cols: int, n_cus: int = 256, nnz: Optional[int] = None) -> Tuple[int, int]:
+def auto_tile_geometry(n_rows: int, n_cols: int, n_cus: int = 256, nnz: Optional[int] = None,
+                       rows_cap: int = 256) -> Tuple[int, int]:
     """(n_row_tiles, n_col_splits), from sweeps at 10k..100k cells (``scratch/geom_mid.py``, ``geom_sweep.py``):
     * many rows (>= 40k): whole rounds of ~195..256-row tiles over the CUs, no column split;
     * fewer rows (the gene side; the cell side of small graphs): ~250-row tiles, and the source axis split so that
       hub rows spread over several workgroups and the launch has ~nnz/50k tiles (between 160 and five full rounds)."""
     min_tiles = -(-n_rows // TILE_ROWS)
     if n_rows >= 40_000:
+        # `rows_cap` < 256 when dedicated loader waves are on: a tile's rows must fit the computing waves' accumulators
+        # (cfg3: 447 -> 512 tiles either way; cfg5's 764,741 rows: 14 rounds of 213-row tiles instead of 12 of 249)
+        min_tiles = -(-n_rows // max(1, min(TILE_ROWS, rows_cap)))
         return -(-min_tiles // n_cus) * n_cus, 1
     n_row_tiles = max(1, -(-n_rows // 250))
     if nnz is not None and nnz >= ONE_ROUND_MIN_NNZ and n_row_tiles <= n_cus:
@@ -512,7 +519,8 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
     vnnz = nnz[vrow] // k_r[vrow] + (vpart < nnz[vrow] % k_r[vrow]).long()  # round-robin share of the row's non-zeros
     min_tiles = -(-V // TILE_ROWS)
     if n_col_splits is None:
-        n_row_tiles, n_col_splits = auto_tile_geometry(V, S, n_cus, total)
+        n_row_tiles, n_col_splits = auto_tile_geometry(V, S, n_cus, total,
+                                                       (TILE_ROWS // TILE_WAVES) * (TILE_WAVES - int(n_loaders or 0)))
     if n_row_tiles is None:
         per = max(1, n_cus // max(1, n_col_splits))
         n_row_tiles = -(-min_tiles // per) * per                 # whole number of rounds over the CUs
@@ -527,8 +535,12 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
     slot_in_wave = rnd // TILE_WAVES
     n_loaders = int(n_loaders or 0)
     rows_per_tile = -(-V // n_row_tiles) if V else 0
-    if n_loaders and rows_per_tile <= (TILE_ROWS // TILE_WAVES) * (TILE_WAVES - n_loaders):
-        cw = TILE_WAVES - n_loaders                                         # computing waves: rows dealt in snake order over them
+    per = TILE_ROWS // TILE_WAVES
+    if n_loaders and rows_per_tile <= per * (TILE_WAVES - n_loaders):
+        # dedicated loader waves: waves 0..L-1 of every tile get no rows (they issue the tile's whole global->LDS stream);
+        # the rows are dealt in snake order over the computing waves.  Measured and dropped (profiles/r03_issue_analysis.md):
+        # equal edge shares per SIMD instead of per wave, a few light rows on the loader waves, loader waves at s_setprio 3.
+        cw = TILE_WAVES - n_loaders
         wave = n_loaders + _snake(rnd, cw)
         slot_in_wave = rnd // cw
     else:

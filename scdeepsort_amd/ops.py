@@ -161,7 +161,7 @@ def agg_bwd_src(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, g: torch.
         alpha = alpha.reshape(-1).float().contiguous()
     if TILED_MIN_WORK is not None and D <= 256 and csr.nnz * D >= TILED_MIN_WORK and csr.ell_cnt is None:
         # K2t: LDS-streamed kernel over the transposed structure; per-destination factors folded into g once
-        tp = t.tile_plan(tiled_block_rows(D), loaders=0)
+        tp = t.tile_plan(tiled_block_rows(D))
         scale = inv_deg if mode != DST_IS_GENE else inv_deg * alpha[: csr.n_rows]
         g = g.contiguous()
         scratch = torch.empty_like(g)
@@ -231,7 +231,7 @@ def agg_bwd_alpha(csr: AggCsr, g: torch.Tensor, h_src: torch.Tensor, h_self: Opt
     d_self = torch.empty(n_out, dtype=torch.float32, device=dev) if h_self is not None else None
     if (TILED_MIN_WORK is not None and row_ids is None and D <= 256 and csr.nnz * D >= TILED_MIN_WORK
             and csr.ell_cnt is None):
-        tp = csr.tile_plan(tiled_block_rows(D), loaders=0)                        # K3t
+        tp = csr.tile_plan(tiled_block_rows(D))                                   # K3t
         h_src = h_src.contiguous()
         part = torch.empty(tp.n_partials * D, dtype=torch.float32, device=dev) if tp.n_partials else None
         n_long = tp.long_rows.shape[0]
@@ -275,7 +275,7 @@ def agg_fwd_tiled(csr: AggCsr, tplan, alpha: Optional[torch.Tensor], mode: int, 
         h_self = _rowmajor(h_self)
     out = torch.empty((csr.n_rows, D), dtype=torch.float32, device=dev)
     flags = (_lib.FLAG_RELU if relu else 0) | (_lib.FLAG_NO_MEAN if no_mean else 0) | \
-            (_lib.FLAG_NO_SELF if h_self is None else 0) | (tplan.n_loaders << 8) | DEBUG_FLAGS
+            (_lib.FLAG_NO_SELF if h_self is None else 0) | DEBUG_FLAGS
     if alpha is not None:
         alpha = alpha.reshape(-1)
         if alpha.dtype != torch.float32 or not alpha.is_contiguous():

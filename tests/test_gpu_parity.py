@@ -1521,3 +1521,43 @@ def test_subplan_with_pathologically_long_rows():
     cgo = O.build_csr_graph(expr)
     zc, _ = O.csr_aggregate(cgo, alpha.cpu().numpy(), hg.cpu().numpy().astype(np.float64), hc.cpu().numpy().astype(np.float64), want_genes=False)
     np.testing.assert_allclose(a.cpu().numpy(), zc[[7, 3, 7, 20]], atol=TOL)
+
+
+# ---- dedicated loader waves of the flat tile kernel (round 3) --------------------------------------------------------
+@pytest.mark.parametrize("kb", [16, 23, 78])
+@pytest.mark.parametrize("D", [64, 200, 256])
+@pytest.mark.parametrize("direction", ["cells", "genes"])
+def test_tile_kernel_dedicated_loader_waves(kb, D, direction):
+    """Dedicated loader waves: a plan built with n_loaders = L deals waves 0..L-1 of every tile no rows, and the kernel makes
+    the leading row-less waves issue the whole global->LDS stream of the steady-state blocks.  Same results as the symmetric
+    plan BIT FOR BIT (the per-row summation order does not depend on which wave streams), equal to the oracle, for L = 1, 2,
+    3, 5; short LDS blocks (kb = 16 / 23) run the steady-state loop and every tail length, kb = 78 the production block
+    height; a plan whose tiles do not fit 16 x (16 - L) rows falls back to L = 0."""
+    from scdeepsort_amd.graph import build_tile_plan
+    from scdeepsort_amd import ops
+    c = small_case(cells=1300, genes=620, dim=D, seed=kb + D, density=0.12, test_cells=40)
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
+    cgo = O.build_csr_graph(c["expr"], c["support_mask"])
+    G = c["G"]; rng = np.random.default_rng(kb)
+    alpha = dev(rng.uniform(0.5, 1.5, G + 2).astype(np.float32)); bias = dev(rng.standard_normal(D).astype(np.float32))
+    Hg, Hc = c["feats"][:G], c["feats"][G:]
+    zc, zg = O.csr_aggregate(cgo, alpha.cpu().numpy(), Hg.astype(np.float64), Hc.astype(np.float64))
+    if direction == "cells":
+        csr, mode, sidx, src, slf, want, geom = g.cg, sda.SRC_IS_GENE, G + 1, dev(Hg), dev(Hc), zc, (8, 1)     # 163 rows per tile
+    else:
+        csr, mode, sidx, src, slf, want, geom = g.gc, sda.DST_IS_GENE, G, dev(Hc), dev(Hg), zg, (4, 2)         # <= 208 virtual rows per tile
+    want = np.maximum(want + bias.cpu().numpy(), 0)
+    run = lambda tp: ops.agg_fwd_tiled(csr, tp, alpha, mode, sidx, src, slf, bias=bias, relu=True)
+    base_plan = build_tile_plan(csr, *geom, block_rows=kb, n_loaders=0)
+    base = run(base_plan)
+    np.testing.assert_allclose(base.cpu().numpy(), want, atol=TOL)
+    for L in (1, 2, 3, 5):
+        tp = build_tile_plan(csr, *geom, block_rows=kb, n_loaders=L)
+        assert tp.n_loaders == L
+        slots = tp.items[:, :, 0].reshape(tp.n_tiles, 16, 16)                     # [tile, wave, row slot] -> row or -1
+        assert (slots[:, :L] < 0).all() and (slots[:, L:] >= 0).any()             # the loader waves own no rows
+        out = run(tp)
+        assert torch.equal(out, base), L
+    crowded = build_tile_plan(csr, 6 if direction == "cells" else 3, geom[1], block_rows=kb, n_loaders=3)   # > 208 rows per tile
+    assert crowded.n_loaders == 0
+    np.testing.assert_allclose(run(crowded).cpu().numpy(), want, atol=TOL)
