@@ -268,7 +268,7 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
                      : [g] "s"(g), [l] "s"(l), [vo] "v"(lane16), [n4] "s"(n4), [ms] "s"(nw * row_bytes), [gs] "s"(nw * 16)
                      : "m0", "memory", "scc", "s90", "s91", "s92", "s93", "s94", "s95");
     };
-    auto fill = [&](int b) { fill_rows(cb + b * kKB, min(kKB, ce - (cb + b * kKB)), b & 1, kTW); };
+    auto fill = [&](int b) { fill_rows(cb + b * kKB, min(kKB, ce - (cb + b * kKB)), b & 1, kTW); };   // every wave its share
     // RIGHT-aligned entry chunk of segment [s, e): with n = min(64, e - s) entries, lane j <- entry s + j - (64 - n);
     // the lanes in front of the chunk replicate its first entry (consume() zeroes their weight).  Always issues exactly
     // one load (the vmcnt bookkeeping depends on it), also for an empty segment (then: any valid entry).
@@ -377,14 +377,74 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
     }
 
     const int4* __restrict__ items = t.tile_items + (size_t)tile * kTileRows + wave * kRPW;
-    for (int i = 0; i < kRPW; ++i) {
-        const int4 it = items[i];
-        const int slot = __builtin_amdgcn_readfirstlane(it.x), pslot = __builtin_amdgcn_readfirstlane(it.w);
-        if (slot < 0) continue;
+    auto acc_row = [&](int i) {                          // accumulator row i of this wave -> compiler registers
         float4 v;
         asm volatile("s_set_gpr_idx_on %4, gpr_idx(SRC0)\n\tv_mov_b32 %0, v64\n\tv_mov_b32 %1, v65\n\t"
                      "v_mov_b32 %2, v66\n\tv_mov_b32 %3, v67\n\ts_set_gpr_idx_off"
                      : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w) : "s"(i * 4) : "m0");
+        return v;
+    };
+    if constexpr (EPI == EPI_FWD && std::is_same<TOut, float>::value) {
+        if (!a.row_ids) {
+            // Forward epilogue, two rows per trip: the rows' item words come through the scalar cache and the self rows of
+            // BOTH rows are requested before either is used.  The row-at-a-time form below chains an item load, an
+            // inv_deg / alpha load and a self-row load per row - ~2 k clk each, 14 rows per wave, ~10 us per tile of pure
+            // latency (the computing waves of a tile all sit in it at the same time).  Same arithmetic, same order.
+            cptr_t sitems = (cptr_t)items;                      // int4 items as dwords: .x at 4 i, .w at 4 i + 3
+            const bool lane_on = lane * 4 < a.D;
+            const bool no_mean = a.flags & WGNN_FLAG_NO_MEAN, relu = a.flags & WGNN_FLAG_RELU;
+            const bool has_self = !(a.flags & WGNN_FLAG_NO_SELF) && a.self != nullptr;
+            const float a_self = has_self ? (a.mode == WGNN_NO_ALPHA ? 1.0f : a.alpha[a.self_idx]) : 0.0f;
+            float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias && lane_on) bias4 = ld4(a.bias + lane * 4);
+            const float* selfp = reinterpret_cast<const float*>(a.self);
+            float* outp = reinterpret_cast<float*>(a.out);
+            for (int i0 = 0; i0 < kRPW; i0 += 2) {
+                int slot[2], pslot[2];
+                float4 sf[2];
+                float invd[2], rs[2];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    slot[k] = sitems[4 * (i0 + k)]; pslot[k] = sitems[4 * (i0 + k) + 3];
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    sf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (slot[k] >= 0 && pslot[k] < 0 && has_self && lane_on)
+                        sf[k] = ld4(selfp + (size_t)slot[k] * a.ld_self + lane * 4);
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    invd[k] = 1.0f; rs[k] = 1.0f;
+                    if (slot[k] >= 0 && pslot[k] < 0) {
+                        if (!no_mean) invd[k] = a.inv_deg ? a.inv_deg[slot[k]] : 1.0f / (row_degree(a, slot[k]) + 1.0f);
+                        rs[k] = invd[k] * (a.mode == WGNN_DST_IS_GENE ? a.alpha[slot[k]] : 1.0f);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    if (slot[k] < 0) continue;
+                    float4 o = acc_row(i0 + k);
+                    if (pslot[k] >= 0) {
+                        if (lane_on) st4(a.partials + (size_t)pslot[k] * a.D + lane * 4, o);
+                        continue;
+                    }
+                    if (a.aux1 && lane_on) st4(a.aux1 + (size_t)slot[k] * a.D + lane * 4, o);      // raw neighbour sum
+                    o.x *= rs[k]; o.y *= rs[k]; o.z *= rs[k]; o.w *= rs[k];
+                    if (has_self) fma4(o, invd[k] * a_self, sf[k]);
+                    if (a.bias) { o.x += bias4.x; o.y += bias4.y; o.z += bias4.z; o.w += bias4.w; }
+                    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                    if (lane_on) st4(outp + (size_t)slot[k] * a.ld_out + lane * 4, o);
+                }
+            }
+            return;
+        }
+    }
+    for (int i = 0; i < kRPW; ++i) {
+        const int4 it = items[i];
+        const int slot = __builtin_amdgcn_readfirstlane(it.x), pslot = __builtin_amdgcn_readfirstlane(it.w);
+        if (slot < 0) continue;
+        const float4 v = acc_row(i);
         if (pslot >= 0) {
             if (lane * 4 < a.D) st4(a.partials + (size_t)pslot * a.D + lane * 4, v);
         } else {

@@ -410,6 +410,11 @@ TILE_WAVES = 16
 # box, 1.29 -> 1.15 on another (L = 1 is bound by the single loader at 1.33 ms, L = 3 by the 13 computing waves at 1.17-1.23).
 # 0 = off.
 TILE_LOADER_WAVES = 2
+# entries per (computing wave, LDS block) from which L loader waves pay (scratch/density_loader.py: cfg3 node counts, density
+# 0.5 .. 8 %): two loaders win from ~20 (tie at 11, -5 % at 5); ONE loader has a floor of ~1.0-1.08 ms per 8.7 GB stream and
+# only pays from ~48 (cfg3's gene side sits at 49)
+LOADER_MIN_ENTRIES = {1: 48.0, 2: 16.0, 3: 16.0}
+VIRTUAL_ROW_SHARE = 0.5   # few-row operands: a row heavier than this share of an average wave's load is dealt as virtual rows
 
 
 @dataclass
@@ -505,22 +510,46 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
     R, S = csr.n_rows, csr.n_cols
     nnz = (csr.rowptr[1:] - csr.rowptr[:-1]).long()
     total = int(nnz.sum())
-    # ---- virtual rows
-    k_r = torch.ones(R, dtype=torch.int64, device=dev)
-    if balance and 0 < R < 40_000 and total > 0:           # many-row operands: every row is a small fraction of a tile
-        tiles_guess = max(n_row_tiles or 0, -(-R // TILE_ROWS), 1)
-        cap = max(64.0, 0.5 * total / (tiles_guess * TILE_WAVES))          # half the average wave's share of a tile
-        k_r = torch.clamp(torch.ceil(nnz.double() / cap).long(), 1, 16)
-    vbase = torch.zeros(R + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(k_r, 0, out=vbase[1:])
-    V = int(vbase[-1])                                                      # number of virtual rows
+    # ---- virtual rows (+ heuristic geometry)
+    n_loaders = int(n_loaders or 0)
+    few_rows = balance and 0 < R < 40_000 and total > 0    # many-row operands: every row is a small fraction of a tile
+    rpw = TILE_ROWS // TILE_WAVES
+    auto_geom = n_col_splits is None
+    if few_rows and n_loaders and auto_geom:
+        # Few-row operands (the gene side) run ONE round of ~250-row tiles: two row-less waves do not fit, one does when the
+        # tile holds <= 240 rows.  cfg3's gene side has 20 600 virtual rows for 85 tiles (243 each); letting a row grow a
+        # little heavier before it is dealt as virtual rows brings that under 85 x 240 - tried in this order.  One loader
+        # wave is enough here because this stream is shorter (8.7 GB; at the cell side's 10.5 GB one loader is the limit):
+        # genes<-cells 1.145-1.16 -> 1.11 ms.
+        n_loaders = 1
+        shares = (VIRTUAL_ROW_SHARE, 0.65, 0.8, 1.0, 1.3)
+    else:
+        shares = (VIRTUAL_ROW_SHARE,)
+    req_tiles, req_splits = n_row_tiles, n_col_splits
+    for attempt, share in enumerate(shares + (VIRTUAL_ROW_SHARE,)):
+        last = attempt == len(shares)                      # nothing fitted: plain plan, every wave streams
+        if last:
+            n_loaders = 0 if few_rows else n_loaders
+        n_row_tiles, n_col_splits = req_tiles, req_splits
+        k_r = torch.ones(R, dtype=torch.int64, device=dev)
+        if few_rows:
+            tiles_guess = max(n_row_tiles or 0, -(-R // TILE_ROWS), 1)
+            cap = max(64.0, share * total / (tiles_guess * TILE_WAVES))      # (half) the average wave's share of a tile
+            k_r = torch.clamp(torch.ceil(nnz.double() / cap).long(), 1, 16)
+        vbase = torch.zeros(R + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(k_r, 0, out=vbase[1:])
+        V = int(vbase[-1])                                                  # number of virtual rows
+        min_tiles = -(-V // TILE_ROWS)
+        if auto_geom:
+            n_row_tiles, n_col_splits = auto_tile_geometry(V, S, n_cus, total, rpw * (TILE_WAVES - n_loaders))
+        if not few_rows or last or n_loaders == 0:
+            break
+        rt = max(n_row_tiles if n_row_tiles is not None else 0, min_tiles, 1)
+        if -(-V // rt) <= rpw * (TILE_WAVES - n_loaders):
+            break
     vrow = torch.repeat_interleave(torch.arange(R, device=dev), k_r)        # virtual row -> row
     vpart = torch.arange(V, device=dev) - vbase[vrow]
     vnnz = nnz[vrow] // k_r[vrow] + (vpart < nnz[vrow] % k_r[vrow]).long()  # round-robin share of the row's non-zeros
-    min_tiles = -(-V // TILE_ROWS)
-    if n_col_splits is None:
-        n_row_tiles, n_col_splits = auto_tile_geometry(V, S, n_cus, total,
-                                                       (TILE_ROWS // TILE_WAVES) * (TILE_WAVES - int(n_loaders or 0)))
     if n_row_tiles is None:
         per = max(1, n_cus // max(1, n_col_splits))
         n_row_tiles = -(-min_tiles // per) * per                 # whole number of rounds over the CUs
@@ -533,10 +562,16 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
         raise ValueError("tile overflow")
     wave = _snake(rnd, TILE_WAVES)
     slot_in_wave = rnd // TILE_WAVES
-    n_loaders = int(n_loaders or 0)
     rows_per_tile = -(-V // n_row_tiles) if V else 0
-    per = TILE_ROWS // TILE_WAVES
-    if n_loaders and rows_per_tile <= per * (TILE_WAVES - n_loaders):
+    if n_loaders and auto_geom:                          # (an explicit geometry takes the requested loader count as given)
+        # Loader waves pay when a block's entry pipeline lasts about as long as the loaders need for the block's 78 pieces
+        # (~4.0 k clk with two loader waves, ~5.7 k with one; an entry costs a computing wave ~110 clk): on sparse operands
+        # (few entries per wave and block) all 16 waves streaming 5 pieces each is faster.
+        nblk_est = max(1, -(-(-(-S // n_col_splits)) // block_rows))
+        per_wave_block = total / max(1, n_row_tiles * n_col_splits * nblk_est * (TILE_WAVES - n_loaders))
+        if per_wave_block < LOADER_MIN_ENTRIES.get(n_loaders, 1e30):
+            n_loaders = 0
+    if n_loaders and rows_per_tile <= rpw * (TILE_WAVES - n_loaders):
         # dedicated loader waves: waves 0..L-1 of every tile get no rows (they issue the tile's whole global->LDS stream);
         # the rows are dealt in snake order over the computing waves.  Measured and dropped (profiles/r03_issue_analysis.md):
         # equal edge shares per SIMD instead of per wave, a few light rows on the loader waves, loader waves at s_setprio 3.
