@@ -25,7 +25,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef WGNN_LIN_BK
 #define WGNN_LIN_BK 16
 #endif
-constexpr int kBM = 128, kBN = 128, kBK = WGNN_LIN_BK, kLd = kBK + 1;
+constexpr int kBM = 128, kBN = 128, kBK = WGNN_LIN_BK, kLd = kBK + 1;      // (the forward kernel's tile height is a template parameter)
+constexpr unsigned WGNN_LIN_FORCE_64 = 1u << 16, WGNN_LIN_FORCE_128 = 1u << 17;   // timing switches of wgnn_linear_fwd_ex
 constexpr int kLinThreads = 256;
 
 struct LinArgs {
@@ -43,8 +44,12 @@ struct LinArgs {
 // out2: a second, row-scaled copy of the result written from the same accumulators - the projected gene table P_g and
 // its alpha-folded form alpha[g] * P_g[g] (the source table of the LDS-streamed cells<-genes pass, models/gnn.py:54's
 // (h * alpha) factor) come out of ONE kernel instead of GEMM + scale_rows.
-template <typename TX, bool DUAL>
+// MI = 32-row MFMA blocks per wave along M: 2 -> 128 x 128 tiles (wave 64 x 64), 1 -> 64 x 128 tiles (wave 32 x 64).  The
+// smaller tile is for operands whose 128-row tiling leaves the last round of workgroups thin (20k rows = 157 x 2 tiles on
+// 256 CUs): twice the tiles, up to 6 workgroups per CU.
+template <typename TX, bool DUAL, int MI>
 __global__ void __launch_bounds__(kLinThreads, 4) linear_mfma_f32(const LinArgs a) {
+    constexpr int kBM = 64 * MI;
     __shared__ float As[2][kBM * kLd];
     __shared__ float Ws[2][kBN * kLd];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -53,9 +58,9 @@ __global__ void __launch_bounds__(kLinThreads, 4) linear_mfma_f32(const LinArgs 
     const long m0 = (long)(blockIdx.x / ((a.N + kBN - 1) / kBN)) * kBM;
     const int n0 = (int)(blockIdx.x % ((a.N + kBN - 1) / kBN)) * kBN;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -64,24 +69,30 @@ __global__ void __launch_bounds__(kLinThreads, 4) linear_mfma_f32(const LinArgs 
     // global -> registers: thread t moves 2 float4 of X and 2 of W per slab (rows t/4 and t/4 + 64, k offset (t%4)*4)
     constexpr int kTPR = kBK / 4;                              // threads per tile row (one float4 each)
     constexpr int kRPP = kLinThreads / kTPR;                   // tile rows covered per pass
-    constexpr int kNP = kBM / kRPP;                            // passes
+    constexpr int kNPA = kBM / kRPP, kNPW = kBN / kRPP;        // passes over the X tile / the W tile
     const int lr = t / kTPR, lk = (t % kTPR) * 4;
-    float4 xa[kNP], wa[kNP];
+    float4 xa[kNPA], wa[kNPW];
     auto gload = [&](int k0) {
+        const bool kin = k0 + lk < a.K;                        // K % 4 == 0: a float4 is inside or outside as a whole
 #pragma unroll
-        for (int i = 0; i < kNP; ++i) {
+        for (int i = 0; i < kNPA; ++i) {
             const long row = m0 + lr + kRPP * i;
-            const int col = n0 + lr + kRPP * i;
-            const bool kin = k0 + lk < a.K;                    // K % 4 == 0: a float4 is inside or outside as a whole
             xa[i] = (row < a.M && kin) ? ld4(reinterpret_cast<const TX*>(a.x) + row * a.ld_x + k0 + lk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < kNPW; ++i) {
+            const int col = n0 + lr + kRPP * i;
             wa[i] = (col < a.N && kin) ? ld4(a.w + (long)col * a.ld_w + k0 + lk) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < kNP; ++i) {
+        for (int i = 0; i < kNPA; ++i) {
             float* pa = &As[buf][(lr + kRPP * i) * kLd + lk];
             pa[0] = xa[i].x; pa[1] = xa[i].y; pa[2] = xa[i].z; pa[3] = xa[i].w;
+        }
+#pragma unroll
+        for (int i = 0; i < kNPW; ++i) {
             float* pw = &Ws[buf][(lr + kRPP * i) * kLd + lk];
             pw[0] = wa[i].x; pw[1] = wa[i].y; pw[2] = wa[i].z; pw[3] = wa[i].w;
         }
@@ -95,16 +106,17 @@ __global__ void __launch_bounds__(kLinThreads, 4) linear_mfma_f32(const LinArgs 
     for (int s = 0; s < nslab; ++s) {
         const int buf = s & 1;
         if (s + 1 < nslab) gload((s + 1) * kBK);               // in flight during this slab's MFMAs
-        const float* pa = &As[buf][(wm * 64 + fr) * kLd + fk];
+        const float* pa = &As[buf][(wm * 32 * MI + fr) * kLd + fk];
         const float* pw = &Ws[buf][(wn * 64 + fr) * kLd + fk];
 #pragma unroll
         for (int kk = 0; kk < kBK; kk += 2) {
-            const float a0 = pa[kk], a1 = pa[32 * kLd + kk];
             const float b0 = pw[kk], b1 = pw[32 * kLd + kk];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const float ai = pa[i * 32 * kLd + kk];
+                acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, b0, acc[i][0], 0, 0, 0);
+                acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ai, b1, acc[i][1], 0, 0, 0);
+            }
         }
         if (s + 1 < nslab) lstore(buf ^ 1);                    // the other buffer: last read two slabs ago
         __syncthreads();
@@ -113,7 +125,7 @@ __global__ void __launch_bounds__(kLinThreads, 4) linear_mfma_f32(const LinArgs 
     // C/D map of the 32x32 forms: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const bool relu = a.flags & WGNN_FLAG_RELU;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 64 + j * 32 + fr;
@@ -121,7 +133,7 @@ __global__ void __launch_bounds__(kLinThreads, 4) linear_mfma_f32(const LinArgs 
             const float bv = a.bias ? a.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
+                const long row = m0 + wm * 32 * MI + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fk;
                 if (row < a.M) {
                     float v = acc[i][j][r] + bv;
                     if (relu) v = fmaxf(v, 0.f);
@@ -272,25 +284,36 @@ extern "C" int wgnn_linear_fwd_ex(const void* x, int x_dtype, int64_t ld_x, cons
                                   float* out, int64_t ld_out, const float* row_scale, float* out_scaled, int64_t ld_out_scaled,
                                   int64_t M, int32_t N, int32_t K, uint32_t flags, void* stream) {
     if (!x || !w || (!out && !out_scaled) || M < 0 || N <= 0 || K <= 0) return WGNN_ERR_BAD_ARG;
-    if (flags & ~WGNN_FLAG_RELU) return WGNN_ERR_BAD_ARG;
+    if (flags & ~(WGNN_FLAG_RELU | WGNN_LIN_FORCE_64 | WGNN_LIN_FORCE_128)) return WGNN_ERR_BAD_ARG;
     if (x_dtype != WGNN_F32 && x_dtype != WGNN_F16) return WGNN_ERR_BAD_ARG;
     if ((out_scaled != nullptr) != (row_scale != nullptr)) return WGNN_ERR_BAD_ARG;
     if (K % 4 || ld_x % 4 || ld_w % 4 || !aligned16(w)) return WGNN_ERR_ALIGNMENT;
     if (x_dtype == WGNN_F32 ? !aligned16(x) : !aligned8(x)) return WGNN_ERR_ALIGNMENT;
     if (ld_x < K || ld_w < K || (out && ld_out < N) || (out_scaled && ld_out_scaled < N)) return WGNN_ERR_BAD_ARG;
     if (M == 0) return WGNN_OK;
-    const long tiles = ((M + kBM - 1) / kBM) * ((N + kBN - 1) / kBN);
+    // tile height: 128 rows, or 64 when that fills the chip's last round of workgroups better (4 resident workgroups per CU
+    // at 128 rows, 6 at 64)
+    const long col_tiles = (N + kBN - 1) / kBN;
+    const long t128 = ((M + 127) / 128) * col_tiles, t64 = ((M + 63) / 64) * col_tiles;
+    auto round_fill = [](long tiles, long slots) { const long r = (tiles + slots - 1) / slots; return (double)tiles / (double)(r * slots); };
+    const bool small = (flags & WGNN_LIN_FORCE_64) || (!(flags & WGNN_LIN_FORCE_128) && round_fill(t64, 256 * 6) > round_fill(t128, 256 * 4) + 0.05);
+    const long tiles = small ? t64 : t128;
     if (tiles > 0x7FFFFFFFL) return WGNN_ERR_UNSUPPORTED;
-    LinArgs a{x, (long)ld_x, w, (long)ld_w, bias, out, (long)ld_out, row_scale, out_scaled, (long)ld_out_scaled, (long)M, N, K, flags};
+    LinArgs a{x, (long)ld_x, w, (long)ld_w, bias, out, (long)ld_out, row_scale, out_scaled, (long)ld_out_scaled, (long)M, N, K,
+              flags & WGNN_FLAG_RELU};
     hipStream_t st = static_cast<hipStream_t>(stream);
     const dim3 grid((unsigned)tiles), block(kLinThreads);
+#define WGNN_LIN_LAUNCH(TX, DUAL)                                                                              \
+    do {                                                                                                       \
+        if (small) hipLaunchKernelGGL((linear_mfma_f32<TX, DUAL, 1>), grid, block, 0, st, a);                  \
+        else hipLaunchKernelGGL((linear_mfma_f32<TX, DUAL, 2>), grid, block, 0, st, a);                        \
+    } while (0)
     if (x_dtype == WGNN_F16) {
-        if (out_scaled) hipLaunchKernelGGL((linear_mfma_f32<__half, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((linear_mfma_f32<__half, false>), grid, block, 0, st, a);
+        if (out_scaled) WGNN_LIN_LAUNCH(__half, true); else WGNN_LIN_LAUNCH(__half, false);
     } else {
-        if (out_scaled) hipLaunchKernelGGL((linear_mfma_f32<float, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((linear_mfma_f32<float, false>), grid, block, 0, st, a);
+        if (out_scaled) WGNN_LIN_LAUNCH(float, true); else WGNN_LIN_LAUNCH(float, false);
     }
+#undef WGNN_LIN_LAUNCH
     return hipGetLastError() == hipSuccess ? WGNN_OK : WGNN_ERR_LAUNCH;
 }
 

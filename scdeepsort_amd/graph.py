@@ -516,20 +516,18 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
     rpw = TILE_ROWS // TILE_WAVES
     auto_geom = n_col_splits is None
     if few_rows and n_loaders and auto_geom:
-        # Few-row operands (the gene side) run ONE round of ~250-row tiles: two row-less waves do not fit, one does when the
-        # tile holds <= 240 rows.  cfg3's gene side has 20 600 virtual rows for 85 tiles (243 each); letting a row grow a
-        # little heavier before it is dealt as virtual rows brings that under 85 x 240 - tried in this order.  One loader
-        # wave is enough here because this stream is shorter (8.7 GB; at the cell side's 10.5 GB one loader is the limit):
-        # genes<-cells 1.145-1.16 -> 1.11 ms.
-        n_loaders = 1
-        shares = (VIRTUAL_ROW_SHARE, 0.65, 0.8, 1.0, 1.3)
+        # Few-row operands run ONE round of ~250-row tiles.  Tried in this order: the requested loader waves as they are (a
+        # 25k-row shard's 214-row tiles hold two); then ONE loader wave, which fits when the tile holds <= 240 rows - cfg3's
+        # gene side has 20 600 virtual rows for 85 tiles (243 each), and letting a row grow a little heavier before it is
+        # dealt as virtual rows brings that under 85 x 240.  One loader wave is enough there because that stream is shorter
+        # (8.7 GB; at the cell side's 10.5 GB one loader is the limit): genes<-cells 1.145-1.16 -> 1.11 ms.
+        candidates = [(n_loaders, VIRTUAL_ROW_SHARE)] + [(1, sh) for sh in (VIRTUAL_ROW_SHARE, 0.65, 0.8, 1.0, 1.3)]
     else:
-        shares = (VIRTUAL_ROW_SHARE,)
+        candidates = [(n_loaders, VIRTUAL_ROW_SHARE)]
+    candidates.append((0 if few_rows else n_loaders, VIRTUAL_ROW_SHARE))    # nothing fitted: plain plan, every wave streams
     req_tiles, req_splits = n_row_tiles, n_col_splits
-    for attempt, share in enumerate(shares + (VIRTUAL_ROW_SHARE,)):
-        last = attempt == len(shares)                      # nothing fitted: plain plan, every wave streams
-        if last:
-            n_loaders = 0 if few_rows else n_loaders
+    for attempt, (n_loaders, share) in enumerate(candidates):
+        last = attempt == len(candidates) - 1
         n_row_tiles, n_col_splits = req_tiles, req_splits
         k_r = torch.ones(R, dtype=torch.int64, device=dev)
         if few_rows:

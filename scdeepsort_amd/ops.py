@@ -461,10 +461,11 @@ def use_wgnn_linear(x: torch.Tensor, weight: torch.Tensor, dual: bool = False) -
 
 
 def linear_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,
-               row_scale: Optional[torch.Tensor] = None):
+               row_scale: Optional[torch.Tensor] = None, tile_rows: Optional[int] = None):
     """``act(x @ weight.T + bias)`` with ``wgnn_linear_fwd_ex`` (v_mfma_f32_32x32x2_f32, exact fp32).  ``x`` may be stored
     in fp16 (widened in registers, no fp32 copy).  With ``row_scale`` ([M]) returns ``(out, row_scale[:, None] * out)``,
-    both written by the one kernel.  Inference helper: no autograd (training keeps torch's Linear, whose backward is a
+    both written by the one kernel.  ``tile_rows`` (64 | 128) overrides the kernel's own choice of tile height (timing
+    experiments).  Inference helper: no autograd (training keeps torch's Linear, whose backward is a
     library GEMM as well)."""
     dev = _require_cuda(x, weight, bias, row_scale)
     if x.dtype not in (torch.float32, torch.float16):
@@ -489,7 +490,7 @@ def linear_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
         bias = bias.float().contiguous()
     rc = _lib.call(dev, "wgnn_linear_fwd_ex", _ptr(x), _dtype_code(x), x.stride(0), _ptr(weight), weight.stride(0), _ptr(bias),
                    _ptr(out), out.stride(0), _ptr(row_scale), _ptr(out2), N if out2 is not None else 0, M, N, K,
-                   _lib.FLAG_RELU if relu else 0, _stream(dev))
+                   (_lib.FLAG_RELU if relu else 0) | {None: 0, 64: 1 << 16, 128: 1 << 17}[tile_rows], _stream(dev))
     _lib.check(rc, "wgnn_linear_fwd_ex")
     return out if out2 is None else (out, out2)
 
