@@ -462,9 +462,20 @@ def auto_tile_geometry(n_rows: int, n_cols: int, n_cus: int = 256, nnz: Optional
         # big operands: ONE round of <= n_cus workgroups.  Every extra column split costs one more partial-sum row per
         # destination row (written, then re-read by agg_finalize); at cfg3 the genes<-cells pass went from 80 x 16
         # tiles / 335 MB of partial sums / 1.42 ms to 85 x 3 / 63 MB / 1.22 ms (scratch/gene_pass_ab.py, round 2).
-        splits = max(1, min(n_cus // n_row_tiles, n_cols // 512 or 1))
-        # fill the round with slightly smaller row tiles (82 -> 85 x 3 = 255 tiles), never by shredding a small operand
-        return max(n_row_tiles, min(n_cus // splits, -(-n_row_tiles * 115 // 100))), splits
+        def one_round(rows_per_tile):
+            rt = max(1, -(-n_rows // rows_per_tile))
+            sp = max(1, min(n_cus // rt, n_cols // 512 or 1))
+            # fill the round with slightly smaller row tiles (82 -> 85 x 3 = 255 tiles), never by shredding a small operand
+            return max(rt, min(n_cus // sp, -(-rt * 115 // 100))), sp
+        plain = one_round(250)
+        if rows_cap < 250:
+            # tiles that leave room for loader waves (<= rows_cap rows) - taken when they still fill the round (a 12.5k-row
+            # shard: 64 x 4 = 256 tiles of 195 rows instead of 51 x 5 of 245; cfg3's gene side would drop to 105 x 2 = 210
+            # tiles of 21 % more work each and keeps 85 x 3)
+            lean = one_round(rows_cap)
+            if lean[0] * lean[1] >= 0.95 * plain[0] * plain[1] and lean[1] <= plain[1]:
+                return lean
+        return plain
     target = 5 * n_cus if nnz is None else min(5 * n_cus, max(160, nnz // 50_000))
     splits = max(1, min(round(target / n_row_tiles), 5 * n_cus // n_row_tiles, n_cols // 512 or 1))
     return n_row_tiles, splits
