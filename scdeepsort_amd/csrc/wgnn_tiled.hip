@@ -232,9 +232,10 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
 
     const int lane16 = lane * 16, row_mask = ~1023;
     // global -> LDS DMA of `rows` source rows starting at global row r0 into LDS buffer `buf`: one 1 KiB row per
-    // wave-instruction, wave w takes rows w, w+16, ...  Scalar base + lane offset addressing: no VALU, 4 SALU per row.
-    auto fill_rows = [&](int r0, int rows, int buf, int nw) {                    // nw = kTW: wave w takes rows w, w+16, ...
-        const int np = rows > wave ? (rows - wave + nw - 1) / nw : 0;          // <= 5 for blocks of <= 80 rows
+    // wave-instruction; the first `nw` waves take part, wave w takes rows w, w + nw, ... (nw = 16: every wave, <= 5 pieces
+    // per block; nw = 2 dedicated loader waves: 39 each).  Scalar base + lane offset addressing: no VALU, 6 SALU per row.
+    auto fill_rows = [&](int r0, int rows, int buf, int nw) {
+        const int np = rows > wave ? (rows - wave + nw - 1) / nw : 0;
         if (np == 0) return;
         const char* g = reinterpret_cast<const char*>(a.src) + ((size_t)r0 + wave) * g_row;
         const int l = (int)(size_t)smem + buf * buf_bytes + wave * row_bytes;
@@ -323,8 +324,6 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
         if (b + 2 < nblk) chunk_issue(nxt_set, ns, ne);
         if (do_comp) compute(cur_set, cs, ce0, (int)(size_t)smem + (b & 1) * buf_bytes);   // smem: the only LDS object
     };
-    // Steady state (b + 3 < nblk, so blocks b+1, b+2, b+3 exist and block b+1 is a full one): no range checks, the
-    // segment pointer / DMA source row / buffer parity advance incrementally.
     // Dedicated loader waves (round 3).  A property of the PLAN: the leading waves of a tile that own no destination rows
     // (graph.build_tile_plan(n_loaders=L) deals them none; a wave's row slots fill from slot 0, so "slot 0 empty" = "no
     // rows") issue the tile's WHOLE global->LDS stream in the steady-state blocks, the other waves only compute.  When
@@ -339,6 +338,8 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
             nld += leading ? 1 : 0;
         }
     }
+    // Steady state (b + 3 < nblk, so blocks b+1, b+2, b+3 exist and block b+1 is a full one): no range checks, the
+    // segment pointer / DMA source row / buffer parity advance incrementally.
     const int* segp = seg + 3 * kTW;                         // -> segment of block b+3
     int fill_row = cb + kKB;                                 // first source row of block b+1
     auto fast_block = [&](auto cur_set, auto nxt_set, int par, int cs, int ce0, int& ns, int& ne) {
