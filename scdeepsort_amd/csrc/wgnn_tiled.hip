@@ -257,17 +257,28 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
         // its 1 KiB LDS slot; the slot's tail is never read by a lane that is stored).  One piece per loop trip: M0 / the
         // 64-bit source address advance by nw rows.
         int left = np;                                        // pieces still to issue (>= 1)
+        // One piece = the DMA, M0 += nw LDS rows, lane offset += nw source rows (v46: a running 32-bit byte offset from the
+        // scalar base - a block's rows span < 4 GiB) - three instructions.  Six pieces per trip while six are left (a
+        // loader wave issues 39 or 78 per block: a lone loader wave is bound by its own instruction issue), then one at a
+        // time.
+#define WGNN_PIECE "global_load_lds_dwordx4 v46, s[94:95]\n\ts_add_u32 m0, m0, %[ms]\n\tv_add_u32 v46, s90, v46\n\t"
         asm volatile("s_mov_b64 s[92:93], exec\n\ts_sub_u32 s91, 64, %[n4]\n\ts_mul_i32 s90, %[n4], %[gs]\n\t"   // s90 = nw rows x D*4 B
                      "s_lshr_b64 exec, s[92:93], s91\n\t"                                                       // lanes 0 .. D/4-1
-                     "s_mov_b64 s[94:95], %[g]\n\ts_mov_b32 m0, %[l]\n\ts_nop 0\n\t"
-                     ".Lw4_fl_%=:\n\t"
-                     "global_load_lds_dwordx4 %[vo], s[94:95]\n\t"
-                     "s_add_u32 m0, m0, %[ms]\n\ts_add_u32 s94, s94, s90\n\ts_addc_u32 s95, s95, 0\n\t"
-                     "s_sub_u32 %[left], %[left], 1\n\ts_cmp_lg_u32 %[left], 0\n\ts_cbranch_scc1 .Lw4_fl_%=\n\t"
+                     "s_mov_b64 s[94:95], %[g]\n\ts_mov_b32 m0, %[l]\n\tv_mov_b32 v46, %[vo]\n\t"
+                     "s_cmp_lt_u32 %[left], 6\n\ts_cbranch_scc1 .Lw4_f1_%=\n\t"
+                     ".Lw4_f6_%=:\n\t"
+                     WGNN_PIECE WGNN_PIECE WGNN_PIECE WGNN_PIECE WGNN_PIECE WGNN_PIECE
+                     "s_sub_u32 %[left], %[left], 6\n\ts_cmp_ge_u32 %[left], 6\n\ts_cbranch_scc1 .Lw4_f6_%=\n\t"
+                     "s_cmp_eq_u32 %[left], 0\n\ts_cbranch_scc1 .Lw4_fe_%=\n\t"
+                     ".Lw4_f1_%=:\n\t"
+                     WGNN_PIECE
+                     "s_sub_u32 %[left], %[left], 1\n\ts_cmp_lg_u32 %[left], 0\n\ts_cbranch_scc1 .Lw4_f1_%=\n\t"
+                     ".Lw4_fe_%=:\n\t"
                      "s_mov_b64 exec, s[92:93]"
                      : [left] "+s"(left)
                      : [g] "s"(g), [l] "s"(l), [vo] "v"(lane16), [n4] "s"(n4), [ms] "s"(nw * row_bytes), [gs] "s"(nw * 16)
-                     : "m0", "memory", "scc", "s90", "s91", "s92", "s93", "s94", "s95");
+                     : "m0", "memory", "scc", "s90", "s91", "s92", "s93", "s94", "s95", "v46");
+#undef WGNN_PIECE
     };
     auto fill = [&](int b) { fill_rows(cb + b * kKB, min(kKB, ce - (cb + b * kKB)), b & 1, kTW); };   // every wave its share
     // RIGHT-aligned entry chunk of segment [s, e): with n = min(64, e - s) entries, lane j <- entry s + j - (64 - n);

@@ -410,10 +410,11 @@ TILE_WAVES = 16
 # box, 1.29 -> 1.15 on another (L = 1 is bound by the single loader at 1.33 ms, L = 3 by the 13 computing waves at 1.17-1.23).
 # 0 = off.
 TILE_LOADER_WAVES = 2
-# entries per (computing wave, LDS block) from which L loader waves pay (scratch/density_loader.py: cfg3 node counts, density
-# 0.5 .. 8 %): two loaders win from ~20 (tie at 11, -5 % at 5); ONE loader has a floor of ~1.0-1.08 ms per 8.7 GB stream and
-# only pays from ~48 (cfg3's gene side sits at 49)
-LOADER_MIN_ENTRIES = {1: 48.0, 2: 16.0, 3: 16.0}
+# Few-row operands (one round of column-split tiles): entries per (computing wave, LDS block) from which L loader waves pay
+# (scratch/density_loader.py, cfg3 node counts, density 0.5 .. 8 %, lean loader loop): one loader wave on the gene side wins
+# from ~30 (0.88 vs 0.97 ms at 37; 0.87 vs 0.79 at 24 - its stream has a floor of ~0.85 ms).  Many-row operands (no column
+# split) gain at every density measured (5 .. 87 entries per wave and block) and are not guarded.
+LOADER_MIN_ENTRIES = {1: 30.0, 2: 16.0, 3: 16.0}
 VIRTUAL_ROW_SHARE = 0.5   # few-row operands: a row heavier than this share of an average wave's load is dealt as virtual rows
 
 
@@ -572,10 +573,9 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
     wave = _snake(rnd, TILE_WAVES)
     slot_in_wave = rnd // TILE_WAVES
     rows_per_tile = -(-V // n_row_tiles) if V else 0
-    if n_loaders and auto_geom:                          # (an explicit geometry takes the requested loader count as given)
-        # Loader waves pay when a block's entry pipeline lasts about as long as the loaders need for the block's 78 pieces
-        # (~4.0 k clk with two loader waves, ~5.7 k with one; an entry costs a computing wave ~110 clk): on sparse operands
-        # (few entries per wave and block) all 16 waves streaming 5 pieces each is faster.
+    if n_loaders and auto_geom and few_rows:             # (an explicit geometry takes the requested loader count as given)
+        # On a one-round operand a lone loader wave has a floor (its ~4 k clk per block of 78 pieces x the blocks of ONE tile):
+        # with few entries per wave and block all 16 waves streaming 5 pieces each is faster.
         nblk_est = max(1, -(-(-(-S // n_col_splits)) // block_rows))
         per_wave_block = total / max(1, n_row_tiles * n_col_splits * nblk_est * (TILE_WAVES - n_loaders))
         if per_wave_block < LOADER_MIN_ENTRIES.get(n_loaders, 1e30):

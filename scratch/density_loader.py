@@ -19,7 +19,7 @@ for dens in (0.005, 0.01, 0.02, 0.03, 0.04, 0.08):
     hg = S.synth_features(G, H, device=dev); hc = S.synth_features(C, H, seed=3, device=dev)
     row = []
     for name, csr, mode, si, src, slf in (("cells", g.cg, sda.SRC_IS_GENE, G + 1, hg, hc), ("genes", g.gc, sda.DST_IS_GENE, G, hc, hg)):
-        for L in (0, 2):
+        for L in (0, 1, 2):
             tp = GR.build_tile_plan(csr, None, None, block_rows=78, n_loaders=L)
             nblk = tp.nblk_max
             e = csr.nnz / (tp.n_tiles * nblk * (16 - tp.n_loaders))

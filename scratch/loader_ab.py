@@ -17,6 +17,7 @@ def timeit(f, n=20):
     for _ in range(n): f()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / n
 kb = 78
+GR.LOADER_MIN_ENTRIES = {1: 0.0, 2: 0.0, 3: 0.0}          # no guard: measure every requested loader count
 Ls = [0] + [x for x in (sys.argv[1:] or ['2', '3'])]
 plans = {}
 for L in Ls:
