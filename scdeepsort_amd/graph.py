@@ -405,11 +405,11 @@ TILE_ROWS = 256          # 16 waves x 16 rows (kTW x kRPW in csrc/wgnn_tiled.hip
 TILE_WAVES = 16
 # Dedicated loader waves of the flat tile kernel (round 3): the first L waves of a tile own no destination rows and issue the
 # whole global->LDS stream of the steady-state blocks; the other 16 - L waves only compute.  Used when a tile's rows fit the
-# remaining 16 x (16 - L) accumulator slots (cfg3's cell side: 195 rows per tile = 14 waves x 14 rows; the gene side's
-# 243-row tiles do not fit and keep 16 symmetric waves).  Same results bit for bit; cfg3 cells<-genes 1.28 -> 1.20 ms on one
+# remaining 16 x (16 - L) accumulator slots (cfg3's cell side: 195 rows per tile = 15 waves x 13 rows at L = 1; the gene side's
+# 243-row tiles are brought under 240 rows, see build_tile_plan).  Same results bit for bit; cfg3 cells<-genes 1.28 -> 1.20 ms on one
 # box, 1.29 -> 1.15 on another (L = 1 is bound by the single loader at 1.33 ms, L = 3 by the 13 computing waves at 1.17-1.23).
 # 0 = off.
-TILE_LOADER_WAVES = 2
+TILE_LOADER_WAVES = 1
 # Few-row operands (one round of column-split tiles): entries per (computing wave, LDS block) from which L loader waves pay
 # (scratch/density_loader.py, cfg3 node counts, density 0.5 .. 8 %, lean loader loop): one loader wave on the gene side wins
 # from ~30 (0.88 vs 0.97 ms at 37; 0.87 vs 0.79 at 24 - its stream has a floor of ~0.85 ms).  Many-row operands (no column

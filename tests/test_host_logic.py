@@ -167,7 +167,8 @@ def test_plan_heuristics():
     assert auto_tile_geometry(10_000, 10_000, nnz=4_000_000) == (42, 6)
     assert auto_tile_geometry(300, 1_000, nnz=30_000) == (3, 1)            # a small operand is never shredded to fill CUs
     assert auto_tile_geometry(300, 100) == (2, 1)
-    # dedicated loader waves (2 of 16): a tile's rows must fit 14 x 16 accumulator rows - cfg3 keeps its 512 tiles, cfg5's
-    # 764,741 rows take 14 rounds of 213-row tiles instead of 12 of 249
-    assert auto_tile_geometry(100_000, 20_000, rows_cap=224) == (512, 1)
+    # dedicated loader waves: a tile's rows must fit the computing waves' accumulator rows (15 x 16 with one loader wave, 14 x 16
+    # with two) - cfg3 keeps its 512 tiles, cfg5's 764,741 rows take 13 / 14 rounds of 230- / 213-row tiles instead of 12 of 249
+    assert auto_tile_geometry(100_000, 20_000, rows_cap=224) == (512, 1) and auto_tile_geometry(100_000, 20_000, rows_cap=240) == (512, 1)
     assert auto_tile_geometry(764_741, 20_000) == (3072, 1) and auto_tile_geometry(764_741, 20_000, rows_cap=224) == (3584, 1)
+    assert auto_tile_geometry(764_741, 20_000, rows_cap=240) == (3328, 1)
