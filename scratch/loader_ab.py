@@ -21,9 +21,9 @@ GR.LOADER_MIN_ENTRIES = {1: 0.0, 2: 0.0, 3: 0.0}          # no guard: measure ev
 Ls = [0] + [x for x in (sys.argv[1:] or ['2', '3'])]
 plans = {}
 for L in Ls:
-    nl, _, lr = str(L).partition('r')
-    GR.LOADER_ROWS = int(lr or 0)
-    plans[L] = GR.build_tile_plan(g.cg, None, None, block_rows=kb, n_loaders=int(nl.rstrip('p')))
+    GR.LOADER_SIMD_BALANCE = str(L).endswith('b')
+    plans[L] = GR.build_tile_plan(g.cg, None, None, block_rows=kb, n_loaders=int(str(L).rstrip('pb')))
+    GR.LOADER_SIMD_BALANCE = False
     seg = plans[L].seg_ptr.long(); cnt = (seg[1:] - seg[:-1]).reshape(-1, 16).float().sum(0)
     print(L, "share of the edges per wave:", [round(x, 3) for x in (cnt / cnt.sum()).tolist()],
           "per SIMD group:", [round(float(cnt[q::4].sum() / cnt.sum()), 3) for q in range(4)], flush=True)
