@@ -18,16 +18,14 @@ def timeit(f, n=20):
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / n
 kb = 78
 GR.LOADER_MIN_ENTRIES = {1: 0.0, 2: 0.0, 3: 0.0}          # no guard: measure every requested loader count
-Ls = [0] + [x for x in (sys.argv[1:] or ['2', '3'])]
+Ls = [x for x in (sys.argv[1:] or ['0', '1', '2'])]
 plans = {}
 for L in Ls:
-    GR.LOADER_SIMD_BALANCE = str(L).endswith('b')
-    plans[L] = GR.build_tile_plan(g.cg, None, None, block_rows=kb, n_loaders=int(str(L).rstrip('pb')))
-    GR.LOADER_SIMD_BALANCE = False
+    plans[L] = GR.build_tile_plan(g.cg, None, None, block_rows=kb, n_loaders=int(str(L).rstrip('ps')))
     seg = plans[L].seg_ptr.long(); cnt = (seg[1:] - seg[:-1]).reshape(-1, 16).float().sum(0)
     print(L, "share of the edges per wave:", [round(x, 3) for x in (cnt / cnt.sum()).tolist()],
           "per SIMD group:", [round(float(cnt[q::4].sum() / cnt.sum()), 3) for q in range(4)], flush=True)
-ref = ops.agg_fwd_tiled(g.cg, plans[0], alpha, sda.SRC_IS_GENE, G + 1, hg, hc)
+ref = ops.agg_fwd_tiled(g.cg, plans[Ls[0]], alpha, sda.SRC_IS_GENE, G + 1, hg, hc)
 res = {}
 for rep in range(int(__import__('os').environ.get('REPS', '5'))):
     for L in Ls:
