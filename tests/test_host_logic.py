@@ -172,3 +172,63 @@ def test_plan_heuristics():
     assert auto_tile_geometry(100_000, 20_000, rows_cap=224) == (512, 1) and auto_tile_geometry(100_000, 20_000, rows_cap=240) == (512, 1)
     assert auto_tile_geometry(764_741, 20_000) == (3072, 1) and auto_tile_geometry(764_741, 20_000, rows_cap=224) == (3584, 1)
     assert auto_tile_geometry(764_741, 20_000, rows_cap=240) == (3328, 1)
+
+
+def _cpu_agg_csr(A):
+    """AggCsr over CPU tensors (the tile-plan builder is pure index arithmetic and runs on any device)."""
+    import scipy.sparse as sp
+    from scdeepsort_amd import graph as GR
+    A = sp.csr_matrix(A); A.sort_indices()
+    rp = torch.from_numpy(A.indptr.astype(np.int32))
+    empty = torch.zeros((0, 4), dtype=torch.int32)
+    return GR.AggCsr(rp, torch.from_numpy(A.indices.astype(np.int32)), torch.from_numpy(A.data.astype(np.float32)),
+                     torch.ones(A.shape[0]), A.shape[0], A.shape[1], GR.Plan(empty, empty, 0, 256), A.indptr.astype(np.int32))
+
+
+def test_tile_plan_with_loader_waves_covers_every_edge_once():
+    """Dedicated loader waves are a property of the tile plan: the first L waves of every tile own no rows, every other
+    wave's slots fill from slot 0 (the kernel reads "slot 0 empty" as "loader wave"), and the re-ordered entries still hold
+    every non-zero of the CSR exactly once with its weight - for explicit geometries with and without column splits, for
+    the heuristic geometry of a many-row and a few-row operand, and for tiles too full to spare a wave (fallback to 0)."""
+    import scipy.sparse as sp
+    from scdeepsort_amd import graph as GR
+    rng = np.random.default_rng(3)
+    X = sp.random(3000, 700, density=0.06, format="csr", random_state=5, dtype=np.float32)
+    X.data = np.abs(X.data) + 0.5
+    Xd = X.toarray(); Xd[:, 3] = 2.0                                      # a hub gene: one row of the gene side is 3000 long
+    X = sp.csr_matrix(Xd)
+    for A, geoms in ((X, [(16, 1, 2), (None, None, 1), (None, None, 2), (12, 1, 3)]),
+                     (sp.csr_matrix(X.T), [(4, 3, 1), (None, None, 1), (3, 2, 2)])):
+        csr = _cpu_agg_csr(A)
+        want = sorted(zip(np.repeat(np.arange(A.shape[0]), np.diff(sp.csr_matrix(A).indptr)).tolist(),
+                          csr.col.tolist(), csr.val.tolist()))
+        for rt, cs, L in geoms:
+            saved = dict(GR.LOADER_MIN_ENTRIES)
+            GR.LOADER_MIN_ENTRIES.update({1: 0.0, 2: 0.0, 3: 0.0})         # small operand: the density guard would switch loaders off
+            try:
+                tp = GR.build_tile_plan(csr, rt, cs, block_rows=32, n_loaders=L)
+            finally:
+                GR.LOADER_MIN_ENTRIES.update(saved)
+            slots = tp.items[:, :, 0].reshape(tp.n_tiles, 16, 16)          # [tile, wave, slot] -> row | -1
+            rows_in_tile = (slots >= 0).sum((1, 2))
+            assert int(rows_in_tile.max()) <= 16 * (16 - tp.n_loaders)
+            if tp.n_loaders:
+                assert (slots[:, : tp.n_loaders] < 0).all()
+            filled = slots >= 0                                            # slots fill from 0: no gap inside a wave
+            assert not (filled[:, :, 1:] & ~filled[:, :, :-1]).any()
+            # decode the entries back to (row, col, val)
+            seg = tp.seg_ptr.long()
+            n_seg = seg.shape[0] - 1
+            per = seg[1:] - seg[:-1]
+            sid = torch.repeat_interleave(torch.arange(n_seg), per)
+            wave = sid % 16
+            blk = (sid // 16) % tp.nblk_max
+            tile = sid // (16 * tp.nblk_max)
+            meta, wbits = tp.entries[:, 0].long(), tp.entries[:, 1]
+            dslot, src_local = meta >> 8, meta & 0xFF
+            row = slots[tile, wave, dslot].long()
+            col = tp.hdr[tile, 0].long() + blk * tp.block_rows + src_local
+            got = sorted(zip(row.tolist(), col.tolist(), wbits.view(torch.float32).tolist()))
+            assert got == want, (rt, cs, L)
+    crowded = GR.build_tile_plan(_cpu_agg_csr(X), 12, 1, block_rows=32, n_loaders=2)      # 250 rows per tile > 14 x 16
+    assert crowded.n_loaders == 0
