@@ -157,8 +157,15 @@ int wgnn_agg_fwd(const void* rowptr /* int32_t[R+1]; int64_t[R+1] with WGNN_FLAG
  *                                          whose slot 0 is empty own no rows - the kernel makes them issue the tile's whole
  *                                          global->LDS stream while the other waves only compute (a plan that gives every
  *                                          wave rows keeps all 16 waves streaming their share; same results either way)
- *   entries    : int32[nnz * 2]            {dst_slot_in_wave << 8 | src_row_in_block, weight (f32 bits)}
- *                                          sorted by (tile, block, wave, dst_slot); block = (col-col_begin)/64
+ *   entries    : int32[n_entries * 2]      {meta, weight (f32 bits)}, grouped by (tile, block, wave) segment;
+ *                                          block = (col - col_begin) / block_rows.  meta = dst_slot_in_wave << 8 |
+ *                                          src_row_in_block (bits 0..11), any order inside a segment, plus optionally
+ *                                          SHARED PAIRS: two entries of a segment on the same source row may be marked
+ *                                          (bit 31 on both, the first also carrying the second's slot in bits 16..19);
+ *                                          the kernel then stages that source row once for both.  Marked pairs must be the
+ *                                          LAST entries of their segment and start at an even offset from the segment's
+ *                                          begin (pad the unmarked run with a zero-weight copy of its last entry; bit 30
+ *                                          marks such a filler for tools, kernels ignore it).  n_entries = nnz + fillers.
  *   seg_ptr    : int32[n_tiles*nblk_max*16 + 1]  entry offsets per (tile, block, wave)
  *   block_rows : source rows per LDS block the plan was built for (16..255; 2*block_rows*D*4 B <= 160 KiB,
  *                at D == 256 minus 4 KiB for the per-wave weight strips, i.e. <= 78)

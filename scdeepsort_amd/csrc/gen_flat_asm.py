@@ -17,6 +17,14 @@ broadcast read of the wave's 256-byte weight strip instead of a second v_readlan
 so every producer is >= 7 instructions ahead of its consumer and no instruction waits on the one before it.
 A chunk of m pairs enters through PRE(32-m): the two warm-up steps without their (meaningless) FMAs.
 
+Shared pairs (round 3).  The plan puts the entries of a segment that read the SAME source row two by two at the END of
+the segment (graph._pair_segment_entries), i.e. in the last pair steps of a chunk.  From step %[sw] on the pipeline
+continues in a second stream (.Lw4_sstep<p>) whose step handles such a pair with ONE readlane, ONE address and ONE row
+read: 6 VALU and 2 LDS operations per pair instead of 8 and 3.  The hand-over is a compare + branch after every unshared
+step (SALU, free): what that step fetched - both entries of pair p+1, both addresses of pair p+2 - is a superset of what
+the shared step expects, and the LDS counter is in order, so there is no drain and no second warm-up.  The first word of
+a shared pair carries 4*slot of the second entry in bits 18..25 (s_lshr -> s_set_gpr_idx_idx).
+
 Register contract (literal registers, hidden from the compiler by amdgpu_num_vgpr / amdgpu_num_sgpr):
     v[64:127]  accumulators (16 destination slots x float4 per lane)
     v[48:55]   staging XA, v[56:63] staging XB
@@ -24,9 +32,10 @@ Register contract (literal registers, hidden from the compiler by amdgpu_num_vgp
     v[40:41]   W0, v[42:43] W1: the two weights of a pair in every lane (op_sel picks the half)
     s[80:85]   three scalar sets {pk0, pk1}; pk = LDS byte address of the source row (a multiple of 1024) | 4*slot:
                its low byte is the GPR index, (pk & %[mk]) | %[lb] the lane's LDS address
-    s92        scratch ; s[94:95] computed-branch target
+    s86        GPR index of a shared pair's second slot ; s92 scratch ; s[94:95] computed-branch target
 Operands: %[pk] (VGPR: packed entry), %[wb] (VGPR, uniform: LDS address of the wave's weight strip, entry j at +4j),
-%[lb] (VGPR: lane*16), %[mk] (VGPR: 0xFFFFFC00), %[m] (SGPR: number of pairs, 1..32).
+%[lb] (VGPR: lane*16), %[mk] (VGPR: 0x3FC00, the row-address bits of a packed entry), %[m] (SGPR: number of pairs,
+1..32), %[sw] (SGPR: first pair step of the shared stream, > 32 - m; 32 = none).
 """
 import os
 import sys
@@ -54,6 +63,8 @@ def wreg(p):
 FMA2 = "fma2" in ABLATE          # v_fma_f32 x4 instead of v_pk_fma_f32 x2 per entry (a REAL variant: results stay correct)
 WRL = "wrl" in ABLATE            # experiment: weights through v_readlane into SGPR pairs instead of the LDS strip
 SCR = 92                         # scratch SGPR of the computed branch
+SSLOT = 86                       # scratch SGPR: GPR index of a shared pair's second slot
+SHARED = DEPTH == 1 and not WRL and "noshared" not in ABLATE    # emit the shared-pair stream (see s_step)
 ORDER = os.environ.get("WGNN_GEN_ORDER", "RLAWF")     # order of a step's groups: R(eads) L(readlanes) W(ait) F(mas) A(ddresses)
 
 
@@ -127,6 +138,49 @@ def fmas(p):
             "s_set_gpr_idx_off"]
 
 
+def s_readlanes(p):
+    return [f"v_readlane_b32 s{sset(p)['pk0']}, %[pk], {2 * p}"]
+
+
+def s_addresses(p):
+    return [f"v_and_or_b32 v44, s{sset(p)['pk0']}, %[mk], %[lb]"]
+
+
+def s_reads(p):
+    x0, _ = xreg(p)
+    w = wreg(p)
+    return [f"ds_read_b128 v[{x0}:{x0 + 3}], v44",
+            f"ds_read_b64 v[{w}:{w + 1}], %[wb] offset:{8 * p}"]
+
+
+def s_fmas(p):
+    """A shared pair: both entries read the SAME source row (one LDS read), the second slot rides in pk0[25:18]."""
+    s = sset(p)
+    x0, _ = xreg(p)
+    w = f"v[{wreg(p)}:{wreg(p) + 1}]"
+    lo, hi = "op_sel_hi:[0,1,1]", "op_sel:[1,0,0] op_sel_hi:[1,1,1]"
+    return [f"s_set_gpr_idx_on s{s['pk0']}, gpr_idx(SRC2,DST)",
+            f"v_pk_fma_f32 v[64:65], {w}, v[{x0}:{x0 + 1}], v[64:65] {lo}",
+            f"v_pk_fma_f32 v[66:67], {w}, v[{x0 + 2}:{x0 + 3}], v[66:67] {lo}",
+            f"s_lshr_b32 s{SSLOT}, s{s['pk0']}, 18",
+            f"s_set_gpr_idx_idx s{SSLOT}",
+            f"v_pk_fma_f32 v[64:65], {w}, v[{x0}:{x0 + 1}], v[64:65] {hi}",
+            f"v_pk_fma_f32 v[66:67], {w}, v[{x0 + 2}:{x0 + 3}], v[66:67] {hi}",
+            "s_set_gpr_idx_off"]
+
+
+def s_step(p):
+    """Shared-pair step p (DEPTH = 1 only): as step(p) with one readlane, one address, one row read per pair.  Entered
+    from the unshared stream after its step p-1, whose fetches (both entries of pair p, both addresses of pair p+1)
+    are a superset of what this step expects; the LDS counter is in order, so lgkmcnt(2) also covers the older three."""
+    out = [f".Lw4_sstep{p}_%=:"]
+    R = s_reads(p + 1) if p + 1 < N_PAIRS else []
+    L = s_readlanes(p + 2) if p + 2 < N_PAIRS else []
+    A = s_addresses(p + 2) if p + 2 < N_PAIRS else []
+    W = [f"s_waitcnt lgkmcnt({2 * min(1, N_PAIRS - 1 - p)})"]
+    return out + R + L + A + W + s_fmas(p)
+
+
 def step(p):
     """Steady-state step p: fetch pair p+DEPTH, prepare pair p+DEPTH+1, accumulate pair p."""
     out = [f".Lw4_step{p}_%=:"]
@@ -151,6 +205,8 @@ def step(p):
         out += ["s_mov_b32 s86, s86", "s_mov_b32 s86, s86"]
     if "xlds" in ABLATE:
         out += ["ds_read_b32 v39, %[wb]"]
+    if SHARED and p + 1 < N_PAIRS:                    # pairs p+1 .. 31 are shared pairs: continue in that stream
+        out += [f"s_cmp_eq_u32 %[sw], {p + 1}", f"s_cbranch_scc1 .Lw4_sstep{p + 1}_%="]
     return out
 
 
@@ -188,6 +244,11 @@ def main(path):
         lines += pre(p0)
     for p in range(N_PAIRS):
         lines += step(p)
+    if SHARED:
+        lines.append("s_branch .Lw4_end_%=")
+        for p in range(1, N_PAIRS):
+            lines += s_step(p)
+        lines.append(".Lw4_end_%=:")
     body = "".join(f'    "{ln}\\n\\t"\n' for ln in lines)
     with open(path, "w") as f:
         f.write("// GENERATED by gen_flat_asm.py - do not edit.  See that file for the register contract.\n")

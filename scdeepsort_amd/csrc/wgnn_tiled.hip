@@ -100,31 +100,21 @@ __global__ void __launch_bounds__(kTW * 64) agg_tiled(const KArgs a, const TArgs
         ent = make_int2(0xFF00, 0);
         if (idx < e) ent = t.entries[idx];
     };
-    // consume one chunk of <= 64 entries (sorted by destination slot) against LDS buffer `lbuf`
+    // consume one chunk of <= 64 entries against LDS buffer `lbuf`, in entry order (any order of slots: the plan
+    // groups a segment's entries for the flat kernel's shared pairs, whose marks in the meta word's high half are
+    // ignored here)
     auto consume = [&](const int2& ent, const char* lbuf) {
-        const int rowl = ent.x >> 8;
-        int e_prev = 0;
+        const int n = __popcll(__ballot((ent.x & 0xFF00) != 0xFF00));
+        for (int j = 0; j < n; ++j) {
+            const int x = __builtin_amdgcn_readlane(ent.x, j);
+            const float w = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ent.y, j));
+            const int slot = (x >> 8) & 0xF;
+            if (active) {
+                const float4 xv = *reinterpret_cast<const float4*>(lbuf + (x & 0xFF) * row_bytes);
 #pragma unroll
-        for (int i = 0; i < kRPW; ++i) {
-            const int e = __popcll(__ballot(rowl <= i));
-            int j = e_prev;
-            for (; j + 1 < e; j += 2) {                       // two independent LDS reads in flight
-                const int c0 = __builtin_amdgcn_readlane(ent.x, j) & 0xFF, c1 = __builtin_amdgcn_readlane(ent.x, j + 1) & 0xFF;
-                const float w0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ent.y, j));
-                const float w1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ent.y, j + 1));
-                if (active) {
-                    const float4 x0 = *reinterpret_cast<const float4*>(lbuf + c0 * row_bytes);
-                    const float4 x1 = *reinterpret_cast<const float4*>(lbuf + c1 * row_bytes);
-                    fma4(acc[i], w0, x0);
-                    fma4(acc[i], w1, x1);
-                }
+                for (int i = 0; i < kRPW; ++i)
+                    if (slot == i) fma4(acc[i], w, xv);
             }
-            if (j < e) {
-                const int c0 = __builtin_amdgcn_readlane(ent.x, j) & 0xFF;
-                const float w0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(ent.y, j));
-                if (active) fma4(acc[i], w0, *reinterpret_cast<const float4*>(lbuf + c0 * row_bytes));
-            }
-            e_prev = e;
         }
     };
     // one source block: `cur*` were loaded a block ago; `nxt*` are loaded now for block b+1
@@ -230,7 +220,7 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
         asm volatile("s_set_gpr_idx_on %0, gpr_idx(DST)\n\tv_mov_b32 v64, 0\n\tv_mov_b32 v65, 0\n\t"
                      "v_mov_b32 v66, 0\n\tv_mov_b32 v67, 0\n\ts_set_gpr_idx_off" ::"s"(r * 4) : WGNN_CLOB);
 
-    const int lane16 = lane * 16, row_mask = ~1023;
+    const int lane16 = lane * 16, row_mask = 0x3FC00;     // LDS row address bits of a packed entry
     // global -> LDS DMA of `rows` source rows starting at global row r0 into LDS buffer `buf`: one 1 KiB row per
     // wave-instruction; the first `nw` waves take part, wave w takes rows w, w + nw, ... (nw = 16: every wave, <= 5 pieces
     // per block; nw = 2 dedicated loader waves: 39 each).  Scalar base + lane offset addressing: no VALU, 6 SALU per row.
@@ -301,12 +291,20 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
     const int wstrip_addr = (int)(size_t)smem + 2 * buf_bytes + wave * 256;
     const int wlane_addr = wstrip_addr + lane * 4;
     auto consume = [&](const int2& ent, int n, int buf_addr) {
-        const int pk = (buf_addr + ((ent.x & 0xFF) << 10)) | ((ent.x >> 8) << 2);   // LDS address of the source row | 4*slot
-        const int wv = lane >= 64 - n ? ent.y : 0;                         // padding lanes: weight 0
+        // packed entry: LDS address of the source row (bits 10..17) | 4*slot (bits 0..7) | 4*slot of the pair's second
+        // entry (bits 18..25; only the first entry of a shared pair carries one)
+        const int pk = (buf_addr + ((ent.x & 0xFF) << 10)) | (((ent.x >> 8) & 0xF) << 2) | (((ent.x >> 16) & 0xF) << 20);
+        const bool mine = lane >= 64 - n;
+        const int wv = mine ? ent.y : 0;                                   // padding lanes: weight 0
         const int m = (n + 1) >> 1;
+        // Shared pairs (two entries of one source row; the plan puts them LAST in a segment, at even offsets) occupy the
+        // last n_s/2 pair steps: from step `sw` on the pipeline continues in its shared-pair stream.  The first pair of a
+        // chunk always runs unshared (the warm-up is that stream's), 32 = never switch.
+        const int n_s = __popcll(__ballot(mine && ent.x < 0));
+        const int sw = max(32 - (n_s >> 1), 33 - m);
         asm volatile("ds_write_b32 %[wa], %[wv]\n\t" WGNN_FLAT4_ASM
                      ::[pk] "v"(pk), [wa] "v"(wlane_addr), [wv] "v"(wv), [wb] "v"(wstrip_addr), [lb] "v"(lane16),
-                       [mk] "v"(row_mask), [m] "s"(m)
+                       [mk] "v"(row_mask), [m] "s"(m), [sw] "s"(sw)
                      : "m0", "memory", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v48", "v63", "v64", "v127",
                        "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93",
                        "s94", "s95");

@@ -199,7 +199,7 @@ class AggCsr:
         pass 0)."""
         if self._tile_plan is None:
             self._tile_plan = {}
-        key = (block_rows, TILE_LOADER_WAVES if loaders is None else loaders)
+        key = (block_rows, TILE_LOADER_WAVES if loaders is None else loaders, TILE_SHARED_PAIRS)
         if key not in self._tile_plan:
             self._tile_plan[key] = build_tile_plan(self, None, None, block_rows=block_rows, n_loaders=key[1])
         return self._tile_plan[key]
@@ -410,12 +410,75 @@ TILE_WAVES = 16
 # box, 1.29 -> 1.15 on another (L = 1 is bound by the single loader at 1.33 ms, L = 3 by the 13 computing waves at 1.17-1.23).
 # 0 = off.
 TILE_LOADER_WAVES = 1
+# Shared pairs: entries of a (wave, block) segment that read the same source row are consumed two per LDS read
+# (_pair_segment_entries; 55 % of the entries at cells<-genes, 43 % at genes<-cells of the headline graph).
+TILE_SHARED_PAIRS = True
+TILE_PAIR_FLAG = -(1 << 31)      # int32 sign bit of an entry's meta word: member of a shared pair
+TILE_PAD_FLAG = 1 << 30          # a zero-weight filler that keeps the pairs at even offsets
 # Few-row operands (one round of column-split tiles): entries per (computing wave, LDS block) from which L loader waves pay
 # (scratch/density_loader.py, cfg3 node counts, density 0.5 .. 8 %, lean loader loop): one loader wave on the gene side wins
 # from ~30 (0.88 vs 0.97 ms at 37; 0.87 vs 0.79 at 24 - its stream has a floor of ~0.85 ms).  Many-row operands (no column
 # split) gain at every density measured (5 .. 87 entries per wave and block) and are not guarded.
 LOADER_MIN_ENTRIES = {1: 30.0, 2: 16.0, 3: 16.0}
 VIRTUAL_ROW_SHARE = 0.5   # few-row operands: a row heavier than this share of an average wave's load is dealt as virtual rows
+
+
+def _pair_segment_entries(seg: torch.Tensor, meta: torch.Tensor, val_bits: torch.Tensor, n_seg: int):
+    """Entries of every (tile, block, wave) segment, ordered for the flat kernel's shared-pair stream.
+
+    Two entries of a segment that read the SAME source row (one gene drawn by two of the wave's 16 cells; one cell
+    expressing two of the wave's genes) form a shared pair: the kernel stages that LDS row once for both.  A segment is
+    laid out as [unshared entries][pad to an even count][shared pairs], so that a pair always starts at an even offset
+    (chunks of 64 never cut one) and the pairs are the LAST pair steps of a right-aligned chunk.  Meta word:
+        unshared / second of a pair : slot << 8 | src_local                    (second: | TILE_PAIR_FLAG)
+        first of a pair             : TILE_PAIR_FLAG | slot_of_second << 16 | slot << 8 | src_local
+        pad                         : TILE_PAD_FLAG | the entry before it, weight 0
+    Returns (entries int32 [n, 2], seg_ptr int64 [n_seg + 1])."""
+    dev = seg.device
+    n = seg.shape[0]
+    meta = meta.long()
+    perm = torch.sort(seg * 256 + (meta & 0xFF), stable=True).indices   # group by (segment, source row), CSR order inside
+    seg_s, meta_s, val_s = seg[perm], meta[perm], val_bits[perm]
+    del perm
+    gkey = seg_s * 256 + (meta_s & 0xFF)
+    ar = torch.arange(n, device=dev)
+    new_group = torch.ones(n, dtype=torch.bool, device=dev)
+    new_group[1:] = gkey[1:] != gkey[:-1]
+    del gkey
+    gid = torch.cumsum(new_group, 0) - 1
+    gstart = ar[new_group]
+    gsize = torch.diff(gstart, append=torch.tensor([n], device=dev))
+    idx_in = ar - gstart[gid]
+    shared = idx_in < (gsize[gid] // 2) * 2
+    first = shared & (idx_in % 2 == 0)
+    del gid, gstart, gsize, new_group
+    # the second entry's slot rides in the first entry's word
+    nxt_slot = torch.zeros_like(meta_s)
+    nxt_slot[:-1] = (meta_s[1:] >> 8) & 0xF
+    meta_s = torch.where(first, meta_s | (nxt_slot << 16), meta_s)
+    del nxt_slot, first, idx_in
+    perm2 = torch.sort(seg_s * 2 + shared.long(), stable=True).indices   # unshared first; pairs stay adjacent
+    seg_s, meta_s, val_s, shared = seg_s[perm2], meta_s[perm2], val_s[perm2], shared[perm2]
+    del perm2
+    n_all = torch.bincount(seg_s, minlength=n_seg)
+    n_sh = torch.bincount(seg_s[shared], minlength=n_seg)
+    pad = (n_all - n_sh) & 1
+    old_ptr = torch.zeros(n_seg + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(n_all, 0, out=old_ptr[1:])
+    seg_ptr = torch.zeros(n_seg + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(n_all + pad, 0, out=seg_ptr[1:])
+    pos = seg_ptr[seg_s] + (ar - old_ptr[seg_s]) + torch.where(shared, pad[seg_s], torch.zeros_like(seg_s))
+    total = int(seg_ptr[-1])
+    meta32 = meta_s.to(torch.int32)
+    meta32 = torch.where(shared, meta32 | torch.tensor(TILE_PAIR_FLAG, dtype=torch.int32, device=dev), meta32)
+    entries = torch.zeros((total, 2), dtype=torch.int32, device=dev)
+    entries[pos, 0] = meta32
+    entries[pos, 1] = val_s
+    pseg = torch.nonzero(pad).squeeze(1)
+    if pseg.numel():
+        ppos = seg_ptr[pseg] + (n_all - n_sh)[pseg]                       # right behind the (odd number of) unshared entries
+        entries[ppos, 0] = (entries[ppos - 1, 0] & 0xFFFF) | TILE_PAD_FLAG
+    return entries, seg_ptr
 
 
 @dataclass
@@ -634,15 +697,20 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
         + wave_v[virt]
     meta = ((slot_v[virt] << 8) | (rel % blk)).to(torch.int32)
     del ksplit, rel, colv
-    key = key * (TILE_ROWS // TILE_WAVES) + slot_v[virt]
-    del virt
-    perm = torch.sort(key, stable=True).indices
     n_seg = n_col_splits * n_row_tiles * nblk_max * TILE_WAVES
-    counts = torch.bincount(torch.div(key, TILE_ROWS // TILE_WAVES, rounding_mode="floor"), minlength=n_seg)
-    del key
-    seg_ptr = torch.zeros(n_seg + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(counts, 0, out=seg_ptr[1:])
-    entries = torch.stack([meta[perm], csr.val.view(torch.int32)[perm]], 1).contiguous()
-    del perm, meta
+    val_bits = csr.val.view(torch.int32)
+    if not TILE_SHARED_PAIRS:
+        key = key * (TILE_ROWS // TILE_WAVES) + slot_v[virt]
+        del virt
+        perm = torch.sort(key, stable=True).indices
+        counts = torch.bincount(torch.div(key, TILE_ROWS // TILE_WAVES, rounding_mode="floor"), minlength=n_seg)
+        del key
+        seg_ptr = torch.zeros(n_seg + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(counts, 0, out=seg_ptr[1:])
+        entries = torch.stack([meta[perm], val_bits[perm]], 1).contiguous()
+        del perm, meta
+    else:
+        entries, seg_ptr = _pair_segment_entries(key, meta, val_bits, n_seg)
+        del key, meta, virt
     return TilePlan(items.contiguous(), hdr.contiguous(), long_rows, n_part,
                     n_row_tiles, n_col_splits, n_loaders, entries, seg_ptr.to(torch.int32), nblk_max, block_rows)

@@ -370,11 +370,13 @@ def test_tiled_plan_covers_every_edge_once():
     g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
     for csr, geom in ((g.cg, (4, 1)), (g.gc, (3, 5))):
         tp = build_tile_plan(csr, *geom)
-        assert tp.entries.shape[0] == csr.nnz
+        from scdeepsort_amd.graph import TILE_PAD_FLAG
+        real = (tp.entries[:, 0] & TILE_PAD_FLAG) == 0               # zero-weight fillers keep shared pairs at even offsets
+        assert int(real.sum()) == csr.nnz and (tp.entries[~real, 1] == 0).all()
         seg = tp.seg_ptr.cpu().numpy()
-        assert seg[0] == 0 and seg[-1] == csr.nnz and (np.diff(seg) >= 0).all()
+        assert seg[0] == 0 and seg[-1] == tp.entries.shape[0] and (np.diff(seg) >= 0).all()
         # weights multiset preserved (bit-exact), every row appears in exactly one (row-)tile per column split
-        assert torch.equal(torch.sort(tp.entries[:, 1]).values, torch.sort(csr.val.view(torch.int32)).values)
+        assert torch.equal(torch.sort(tp.entries[real, 1]).values, torch.sort(csr.val.view(torch.int32)).values)
         # tiles of one column split share a source range (tile_hdr); their launch order is XCD-aware (graph._flat_tile_index)
         begins = tp.hdr[:, 0].cpu().numpy()
         split_of = np.searchsorted(np.unique(begins), begins)
@@ -1530,8 +1532,8 @@ def test_subplan_with_pathologically_long_rows():
 def test_tile_kernel_dedicated_loader_waves(kb, D, direction):
     """Dedicated loader waves: a plan built with n_loaders = L deals waves 0..L-1 of every tile no rows, and the kernel makes
     the leading row-less waves issue the whole global->LDS stream of the steady-state blocks.  Same results as the symmetric
-    plan BIT FOR BIT (the per-row summation order does not depend on which wave streams), equal to the oracle, for L = 1, 2,
-    3, 5; short LDS blocks (kb = 16 / 23) run the steady-state loop and every tail length, kb = 78 the production block
+    plan BIT FOR BIT with slot-sorted entries (the per-row summation order does not depend on which wave streams), equal to
+    the oracle with and without shared pairs, for L = 1, 2, 3, 5; short LDS blocks (kb = 16 / 23) run the steady-state loop and every tail length, kb = 78 the production block
     height; a plan whose tiles do not fit 16 x (16 - L) rows falls back to L = 0."""
     from scdeepsort_amd.graph import build_tile_plan
     from scdeepsort_amd import ops
@@ -1548,16 +1550,81 @@ def test_tile_kernel_dedicated_loader_waves(kb, D, direction):
         csr, mode, sidx, src, slf, want, geom = g.gc, sda.DST_IS_GENE, G, dev(Hc), dev(Hg), zg, (4, 2)         # <= 208 virtual rows per tile
     want = np.maximum(want + bias.cpu().numpy(), 0)
     run = lambda tp: ops.agg_fwd_tiled(csr, tp, alpha, mode, sidx, src, slf, bias=bias, relu=True)
-    base_plan = build_tile_plan(csr, *geom, block_rows=kb, n_loaders=0)
-    base = run(base_plan)
-    np.testing.assert_allclose(base.cpu().numpy(), want, atol=TOL)
-    for L in (1, 2, 3, 5):
-        tp = build_tile_plan(csr, *geom, block_rows=kb, n_loaders=L)
-        assert tp.n_loaders == L
-        slots = tp.items[:, :, 0].reshape(tp.n_tiles, 16, 16)                     # [tile, wave, row slot] -> row or -1
-        assert (slots[:, :L] < 0).all() and (slots[:, L:] >= 0).any()             # the loader waves own no rows
-        out = run(tp)
-        assert torch.equal(out, base), L
+    from scdeepsort_amd import graph as GR
+    was = GR.TILE_SHARED_PAIRS
+    try:
+        for pairs in (False, True):
+            # slot-sorted entries: a row's summation order is its CSR order whatever the wave -> bit-identical across L;
+            # shared pairs order a row's entries by what its wave-mates share with it -> equal to rounding
+            GR.TILE_SHARED_PAIRS = pairs
+            base_plan = build_tile_plan(csr, *geom, block_rows=kb, n_loaders=0)
+            assert bool((base_plan.entries[:, 0] < 0).any()) == pairs
+            base = run(base_plan)
+            np.testing.assert_allclose(base.cpu().numpy(), want, atol=TOL)
+            for L in (1, 2, 3, 5):
+                tp = build_tile_plan(csr, *geom, block_rows=kb, n_loaders=L)
+                assert tp.n_loaders == L
+                slots = tp.items[:, :, 0].reshape(tp.n_tiles, 16, 16)                 # [tile, wave, row slot] -> row or -1
+                assert (slots[:, :L] < 0).all() and (slots[:, L:] >= 0).any()         # the loader waves own no rows
+                out = run(tp)
+                if pairs:
+                    np.testing.assert_allclose(out.cpu().numpy(), want, atol=TOL)
+                else:
+                    assert torch.equal(out, base), L
+    finally:
+        GR.TILE_SHARED_PAIRS = was
     crowded = build_tile_plan(csr, 6 if direction == "cells" else 3, geom[1], block_rows=kb, n_loaders=3)   # > 208 rows per tile
     assert crowded.n_loaders == 0
     np.testing.assert_allclose(run(crowded).cpu().numpy(), want, atol=TOL)
+
+
+@pytest.mark.parametrize("density", [0.01, 0.08, 0.5, 0.95])
+@pytest.mark.parametrize("D", [64, 256])
+def test_tile_kernel_shared_pairs(density, D):
+    """Shared pairs of agg_tiled_flat4 (graph._pair_segment_entries): entries of a (wave, block) segment on the same source
+    row are consumed two per LDS read by the pipeline's second stream.  Densities from "no pair in most segments" to "every
+    entry paired, ~15 chunks of 64 per segment" (the multi-chunk loop, chunks that are all pairs, pads after an odd
+    unshared run), both directions, against the oracle; the slot-sorted plan of the same graph must agree to rounding, and
+    the generic tile kernel (entry order free) reads the same paired plan."""
+    from scdeepsort_amd.graph import build_tile_plan
+    from scdeepsort_amd import ops, graph as GR
+    c = small_case(cells=700, genes=330, dim=D, seed=int(density * 100) + D, density=density, test_cells=30)
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
+    cgo = O.build_csr_graph(c["expr"], c["support_mask"])
+    G = c["G"]; rng = np.random.default_rng(D)
+    alpha = dev(rng.uniform(0.5, 1.5, G + 2).astype(np.float32))
+    Hg, Hc = c["feats"][:G], c["feats"][G:]
+    zc, zg = O.csr_aggregate(cgo, alpha.cpu().numpy(), Hg.astype(np.float64), Hc.astype(np.float64))
+    was = GR.TILE_SHARED_PAIRS
+    try:
+        for csr, mode, sidx, src, slf, want, geom in ((g.cg, sda.SRC_IS_GENE, G + 1, dev(Hg), dev(Hc), zc, (4, 1)),
+                                                       (g.gc, sda.DST_IS_GENE, G, dev(Hc), dev(Hg), zg, (2, 3))):
+            outs = {}
+            for pairs in (False, True):
+                GR.TILE_SHARED_PAIRS = pairs
+                for kb, L in ((78, 1), (23, 0), (64, 2)):
+                    tp = build_tile_plan(csr, *geom, block_rows=kb, n_loaders=L)
+                    meta = tp.entries[:, 0]
+                    if not pairs:
+                        assert not (meta < 0).any()
+                    elif density >= 0.5:
+                        assert float((meta < 0).float().mean()) > 0.5
+                        seg = tp.seg_ptr.long()
+                        if kb == 78:
+                            assert int((seg[1:] - seg[:-1]).max()) > 64            # more than one chunk of 64 per segment
+                    out = ops.agg_fwd_tiled(csr, tp, alpha, mode, sidx, src, slf)
+                    np.testing.assert_allclose(out.cpu().numpy(), want, atol=TOL, rtol=1e-5)
+                    outs[(pairs, kb)] = out
+                    if pairs and kb == 78:
+                        ops.DEBUG_FLAGS = 1 << 19                                   # the generic tile kernel
+                        try:
+                            gen = ops.agg_fwd_tiled(csr, tp, alpha, mode, sidx, src, slf)
+                        finally:
+                            ops.DEBUG_FLAGS = 0
+                        np.testing.assert_allclose(gen.cpu().numpy(), want, atol=TOL, rtol=1e-5)
+                        again = ops.agg_fwd_tiled(csr, tp, alpha, mode, sidx, src, slf)
+                        assert torch.equal(again, out)                             # deterministic
+            for kb in (78, 23, 64):
+                np.testing.assert_allclose(outs[(True, kb)].cpu().numpy(), outs[(False, kb)].cpu().numpy(), atol=2e-5, rtol=1e-5)
+    finally:
+        GR.TILE_SHARED_PAIRS = was

@@ -141,18 +141,23 @@ def test_generated_flat_pipeline_is_in_sync_and_well_formed(tmp_path):
     lines = [l.strip().strip('"\\ ').replace("\\n\\t", "") for l in out.read_text().splitlines() if l.strip().startswith('"')]
     labels = {l[:-1] for l in lines if l.endswith(":")}
     for l in lines:
-        m = re.match(r"s_branch (\S+)", l)
+        m = re.match(r"s_c?branch(?:_scc1)? (\S+)", l)
         if m:
             assert m.group(1) in labels, l
     assert sum(1 for l in labels if "_step" in l) == 32 and sum(1 for l in labels if "_pre" in l) == 32
-    # per step: reads of pair p+1 (3 LDS ops) are outstanding when pair p is consumed
+    assert sum(1 for l in labels if "_sstep" in l) == 31
+    # per step: reads of pair p+1 (3 LDS ops; 2 in the shared-pair stream) are outstanding when pair p is consumed
     text = "\n".join(lines)
-    for p in range(32):
-        body = text.split(f".Lw4_step{p}_%=:")[1].split(".Lw4_step")[0]
-        n_reads = len(re.findall(r"ds_read_b(128|64)", body))
-        wait = int(re.search(r"s_waitcnt lgkmcnt\((\d+)\)", body).group(1))
-        assert n_reads == (3 if p < 31 else 0) and wait == n_reads, (p, n_reads, wait)
-        assert len(re.findall(r"v_pk_fma_f32", body)) == 4
+    for stream, n_ops in (("step", 3), ("sstep", 2)):
+        for p in range(32 if stream == "step" else 1, 32):
+            body = re.split(r"\.Lw4_s?step\d+_%=:|\.Lw4_end_%=:", text.split(f".Lw4_{stream}{p}_%=:")[1])[0]
+            n_reads = len(re.findall(r"ds_read_b(128|64)", body))
+            wait = int(re.search(r"s_waitcnt lgkmcnt\((\d+)\)", body).group(1))
+            assert n_reads == (n_ops if p < 31 else 0) and wait == n_reads, (stream, p, n_reads, wait)
+            assert len(re.findall(r"v_pk_fma_f32", body)) == 4
+            assert len(re.findall(r"v_readlane_b32", body)) == (0 if p >= 30 else n_ops - 1)
+            if stream == "step" and p < 31:          # hand-over to the shared-pair stream after every unshared step
+                assert f"s_cmp_eq_u32 %[sw], {p + 1}" in body and f"s_cbranch_scc1 .Lw4_sstep{p + 1}_%=" in body
 
 
 def test_plan_heuristics():
@@ -225,10 +230,26 @@ def test_tile_plan_with_loader_waves_covers_every_edge_once():
             blk = (sid // 16) % tp.nblk_max
             tile = sid // (16 * tp.nblk_max)
             meta, wbits = tp.entries[:, 0].long(), tp.entries[:, 1]
-            dslot, src_local = meta >> 8, meta & 0xFF
+            dslot, src_local = (meta >> 8) & 0xF, meta & 0xFF
+            paired, padded = meta < 0, (meta & GR.TILE_PAD_FLAG) != 0
+            # shared pairs: the LAST entries of a segment, at even offsets, both members on one source row, the first
+            # carrying the second's slot; pads: zero weight, only between an odd unshared run and the pairs
+            off = torch.arange(meta.shape[0]) - seg[sid]
+            assert (wbits[padded] == 0).all() and not (paired & padded).any()
+            assert int(paired.sum()) % 2 == 0
+            first = torch.nonzero(paired & (off % 2 == 0)).squeeze(1)
+            assert first.numel() * 2 == int(paired.sum())
+            assert paired[first + 1].all() and (sid[first + 1] == sid[first]).all()
+            assert (src_local[first + 1] == src_local[first]).all()
+            assert (((meta[first] >> 16) & 0xF) == dslot[first + 1]).all()
+            n_pair = torch.bincount(sid[paired], minlength=n_seg)
+            assert (paired == (off >= (per - n_pair)[sid])).all()                  # pairs close their segment
+            assert ((per - n_pair) % 2 == 0).all()
+            assert paired.any()
+            keep = ~padded
             row = slots[tile, wave, dslot].long()
             col = tp.hdr[tile, 0].long() + blk * tp.block_rows + src_local
-            got = sorted(zip(row.tolist(), col.tolist(), wbits.view(torch.float32).tolist()))
+            got = sorted(zip(row[keep].tolist(), col[keep].tolist(), wbits[keep].view(torch.float32).tolist()))
             assert got == want, (rt, cs, L)
     crowded = GR.build_tile_plan(_cpu_agg_csr(X), 12, 1, block_rows=32, n_loaders=2)      # 250 rows per tile > 14 x 16
     assert crowded.n_loaders == 0
