@@ -205,6 +205,9 @@ def main():
         self_launch(args)                                        # does not return
     rank = int(os.environ.get("RANK", 0)); local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if os.environ.get("WGNN_BENCH_DUMP_AFTER"):                  # debugging aid: every rank prints its Python stack after N s
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["WGNN_BENCH_DUMP_AFTER"]), repeat=False, exit=False)
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} rank(s)")
     share = os.environ.get("WGNN_BENCH_SHARE_GPU") == "1"        # debug: the N>1 path on a 1-GPU box (all ranks on cuda:0)

@@ -4,6 +4,10 @@ repetitions; parity of each against the row-wave kernel."""
 import sys, json, os, torch
 sys.path.insert(0, '/root/repo')
 import scdeepsort_amd as sda
+from scdeepsort_amd import _lib
+if os.environ.get('WGNN_LIB'):
+    from pathlib import Path
+    _lib.LIB_PATH = Path(os.environ['WGNN_LIB'])              # A/B against another build of the library
 from scdeepsort_amd import synthetic as S, ops, graph as GR
 dev = 'cuda:0'
 cfg = S.CONFIGS[os.environ.get('CFG', 'cfg3')]; G, C, H = cfg.genes, cfg.cells, 256

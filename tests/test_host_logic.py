@@ -149,7 +149,7 @@ def test_generated_flat_pipeline_is_in_sync_and_well_formed(tmp_path):
     # per step: reads of pair p+1 (3 LDS ops; 2 in the shared-pair stream) are outstanding when pair p is consumed
     text = "\n".join(lines)
     for stream, n_ops in (("step", 3), ("sstep", 2)):
-        for p in range(32 if stream == "step" else 1, 32):
+        for p in range(0 if stream == "step" else 1, 32):
             body = re.split(r"\.Lw4_s?step\d+_%=:|\.Lw4_end_%=:", text.split(f".Lw4_{stream}{p}_%=:")[1])[0]
             n_reads = len(re.findall(r"ds_read_b(128|64)", body))
             wait = int(re.search(r"s_waitcnt lgkmcnt\((\d+)\)", body).group(1))
