@@ -42,11 +42,13 @@
 extern "C" {
 #endif
 
-#define WGNN_VERSION 200           /* 0.2.0 - INCOMPATIBLE with 0.1.x binders: `neigh_sum` was inserted before `n_out` in
+#define WGNN_VERSION 201           /* 0.2.x - INCOMPATIBLE with 0.1.x binders: `neigh_sum` was inserted before `n_out` in
                                       wgnn_agg_fwd / wgnn_agg_fwd_tiled (0.1.1, should have been a major bump then - a 0.1.0
                                       caller would pass n_out in a pointer slot); 0.2.0 adds int64 row pointers
                                       (WGNN_FLAG_ROWPTR_I64, wgnn_normalize_rows_i64), WGNN_FLAG_SRC_PRESCALED and
-                                      wgnn_linear_fwd_ex.  Binders must check wgnn_version() / 100 == 2. */
+                                      wgnn_linear_fwd_ex.  Binders must check wgnn_version() / 100 == 2.
+                                      0.2.1: tile-plan entries may mark shared pairs (see wgnn_agg_fwd_tiled); a 0.2.0
+                                      library would misread the marks, so a plan that carries them needs >= 201. */
 
 /* error codes */
 #define WGNN_OK                 0

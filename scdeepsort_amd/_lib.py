@@ -16,6 +16,7 @@ SRC_IS_GENE, DST_IS_GENE, NO_ALPHA = 0, 1, 2
 F32, F16 = 0, 1
 FLAG_RELU, FLAG_NO_MEAN, FLAG_NO_SELF, FLAG_SELF_COMPACT, FLAG_ROWPTR_I64, FLAG_SRC_PRESCALED = 1, 2, 4, 8, 16, 32
 ABI_MAJOR = 2                      # include/wgnn.h WGNN_VERSION / 100
+ABI_MIN = 201                      # shared-pair marks in tile-plan entries (graph._pair_segment_entries) need 0.2.1
 
 _vp, _i32, _i64, _u32, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_int
 
@@ -67,8 +68,9 @@ def lib() -> C.CDLL:
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(dll, name)          # AttributeError here = header/ABI drift
         fn.restype, fn.argtypes = res, args
-    if dll.wgnn_version() // 100 != ABI_MAJOR:
-        raise WgnnError(f"{LIB_PATH} speaks ABI {dll.wgnn_version()}, this binding needs major version {ABI_MAJOR}: rebuild it")
+    if dll.wgnn_version() // 100 != ABI_MAJOR or dll.wgnn_version() < ABI_MIN:
+        raise WgnnError(f"{LIB_PATH} speaks ABI {dll.wgnn_version()}, this binding needs major version {ABI_MAJOR}, "
+                        f"at least {ABI_MIN}: rebuild it")
     return dll
 
 
