@@ -428,7 +428,7 @@ def _pair_segment_entries(seg: torch.Tensor, meta: torch.Tensor, val_bits: torch
 
     Two entries of a segment that read the SAME source row (one gene drawn by two of the wave's 16 cells; one cell
     expressing two of the wave's genes) form a shared pair: the kernel stages that LDS row once for both.  A segment is
-    laid out as [unshared entries][pad to an even count][shared pairs], so that a pair always starts at an even offset
+    laid out as [unshared entries][pad to an even count, if pairs follow][shared pairs], so that a pair always starts at an even offset
     (chunks of 64 never cut one) and the pairs are the LAST pair steps of a right-aligned chunk.  Meta word:
         unshared / second of a pair : slot << 8 | src_local                    (second: | TILE_PAIR_FLAG)
         first of a pair             : TILE_PAIR_FLAG | slot_of_second << 16 | slot << 8 | src_local
@@ -462,7 +462,7 @@ def _pair_segment_entries(seg: torch.Tensor, meta: torch.Tensor, val_bits: torch
     del perm2
     n_all = torch.bincount(seg_s, minlength=n_seg)
     n_sh = torch.bincount(seg_s[shared], minlength=n_seg)
-    pad = (n_all - n_sh) & 1
+    pad = ((n_all - n_sh) & 1) * (n_sh > 0).long()                        # only where pairs follow the unshared run
     old_ptr = torch.zeros(n_seg + 1, dtype=torch.int64, device=dev)
     torch.cumsum(n_all, 0, out=old_ptr[1:])
     seg_ptr = torch.zeros(n_seg + 1, dtype=torch.int64, device=dev)

@@ -244,7 +244,8 @@ def test_tile_plan_with_loader_waves_covers_every_edge_once():
             assert (((meta[first] >> 16) & 0xF) == dslot[first + 1]).all()
             n_pair = torch.bincount(sid[paired], minlength=n_seg)
             assert (paired == (off >= (per - n_pair)[sid])).all()                  # pairs close their segment
-            assert ((per - n_pair) % 2 == 0).all()
+            assert ((per - n_pair)[n_pair > 0] % 2 == 0).all()
+            assert (torch.bincount(sid[padded], minlength=n_seg)[n_pair == 0] == 0).all()      # no pad without pairs
             assert paired.any()
             keep = ~padded
             row = slots[tile, wave, dslot].long()
