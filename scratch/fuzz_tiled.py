@@ -4,12 +4,13 @@ import scipy.sparse as sp
 import scdeepsort_amd as sda
 from scdeepsort_amd import ops
 from scdeepsort_amd.graph import build_tile_plan
+from scdeepsort_amd import graph as GR
 dev='cuda:0'
 rng=np.random.default_rng(int(sys.argv[1]) if len(sys.argv)>1 else 0)
 ops.TILED_MIN_WORK=None
 worst=0
 for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 60):
-    C=int(rng.integers(20,3000)); G=int(rng.integers(10,1500)); dens=float(rng.uniform(0.005,0.4))
+    C=int(rng.integers(20,3000)); G=int(rng.integers(10,1500)); dens=float(rng.choice([rng.uniform(0.005,0.4), rng.uniform(0.4,0.98)], p=[0.75,0.25]))
     D=int(rng.choice([256,256,256,128,64,200]))
     m=rng.random((C,G))<dens
     if rng.random()<0.5: m[:, rng.integers(0,G)] = True            # a hub gene
@@ -22,10 +23,12 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 60):
     kb=int(rng.integers(16,79))
     for csr,mode,si,hs,hself in ((g.cg,sda.SRC_IS_GENE,G+1,hg,hc),(g.gc,sda.DST_IS_GENE,G,hc,hg)):
         rt=int(rng.integers(1,8)); cs=int(rng.integers(1,6))
-        tp=build_tile_plan(csr, None if rng.random()<0.3 else max(rt,-(-csr.n_rows//256)), cs, block_rows=kb)
+        GR.TILE_SHARED_PAIRS = bool(rng.random() < 0.8)               # shared pairs (round 3) on most draws
+        L = int(rng.choice([0, 0, 1, 2, 3]))                          # dedicated loader waves (falls back to 0 if the tile is too tall)
+        tp=build_tile_plan(csr, None if rng.random()<0.3 else max(rt,-(-csr.n_rows//256)), cs, block_rows=kb, n_loaders=L)
         ref=ops.agg_fwd(csr,alpha,mode,si,hs,hself)
         out=ops.agg_fwd_tiled(csr,tp,alpha,mode,si,hs,hself)
         err=float((ref-out).abs().max()); worst=max(worst,err)
         if not err < 1e-4:
-            print('MISMATCH',it,C,G,dens,D,kb,rt,cs,err); sys.exit(1)
+            print('MISMATCH',it,C,G,dens,D,kb,rt,cs,L,GR.TILE_SHARED_PAIRS,err); sys.exit(1)
 print('fuzz ok, worst abs diff', worst)
