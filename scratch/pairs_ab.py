@@ -33,7 +33,9 @@ for name, csr, kind, self_idx, src, slf in (("cells<-genes", g.cg, sda.SRC_IS_GE
         m = tp.entries[:, 0]
         print(name, "pairs" if pairs else "plain", "entries", tp.entries.shape[0], "in pairs", int((m < 0).sum()),
               "pads", int(((m & GR.TILE_PAD_FLAG) != 0).sum()), "loaders", tp.n_loaders, flush=True)
-    ref = ops.agg_fwd(csr, alpha, kind, self_idx, src, slf)                  # the row-wave kernel
+    tmw, ops.TILED_MIN_WORK = ops.TILED_MIN_WORK, None                       # the reference: the row-wave kernel (no tile dispatch)
+    ref = ops.agg_fwd(csr, alpha, kind, self_idx, src, slf)
+    ops.TILED_MIN_WORK = tmw
     for rep in range(int(os.environ.get('REPS', '4'))):
         for pairs in (False, True):
             tp = plans[pairs]
