@@ -406,8 +406,9 @@ TILE_WAVES = 16
 # Dedicated loader waves of the flat tile kernel (round 3): the first L waves of a tile own no destination rows and issue the
 # whole global->LDS stream of the steady-state blocks; the other 16 - L waves only compute.  Used when a tile's rows fit the
 # remaining 16 x (16 - L) accumulator slots (cfg3's cell side: 195 rows per tile = 15 waves x 13 rows at L = 1; the gene side's
-# 243-row tiles are brought under 240 rows, see build_tile_plan).  Same results bit for bit; cfg3 cells<-genes 1.28 -> 1.20 ms on one
-# box, 1.29 -> 1.15 on another (L = 1 is bound by the single loader at 1.33 ms, L = 3 by the 13 computing waves at 1.17-1.23).
+# 243-row tiles are brought under 240 rows, see build_tile_plan).  Which wave streams does not change a row's summation order (with slot-sorted entries the results
+# are the same bit for bit; shared pairs order a row's entries by its wave-mates, so plans then agree to rounding).  First form:
+# cfg3 cells<-genes 1.28 -> 1.20 ms on one box, 1.29 -> 1.15 on another; with the lean piece loop L = 1 is the default.
 # 0 = off.
 TILE_LOADER_WAVES = 1
 # Shared pairs: entries of a (wave, block) segment that read the same source row are consumed two per LDS read
