@@ -112,6 +112,9 @@ class LocalOps:
                                #  self_compact: p_c_local already holds one row per entry of rows)
     genes_partial: Callable    # (p_c_local)                               -> partial [G, H] (plain weighted sum)
     genes_finish: Callable     # (partial_sum_global, p_g, bias, relu)     -> h_g'
+    cells_mean_linear: Optional[Callable] = None   # (h_g, h_c_local, W, bias, relu[, rows, self_compact]) -> the LAST layer in the
+                               #  reference's literal order, act(mean-aggregation W^T + b): at equal widths it skips the
+                               #  replicated [G, H] x [H, H] product of project-first (used when nothing is differentiated)
 
 
 def dropout_mask(shape, p: float, generator: Optional[torch.Generator], device, dtype=torch.float32) -> torch.Tensor:
@@ -146,6 +149,11 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
             if compact:
                 m_c = m_c[seeds_local.long()]
             h_g, h_c = h_g.to(m_g.dtype) * m_g, h_c.to(m_c.dtype) * m_c
+        if (last and ops.cells_mean_linear is not None and W.shape[0] == W.shape[1] and h_g.dtype == W.dtype
+                and not torch.is_grad_enabled()):
+            h_c = (ops.cells_mean_linear(h_g, h_c, W, b, relu) if rows is None
+                   else ops.cells_mean_linear(h_g, h_c, W, b, relu, rows, compact))
+            break
         if getattr(linear, "widens_fp16", False):       # ops.linear: fp16-stored rows are widened inside the GEMM's loader
             p_g, p_c = linear(h_g, W), linear(h_c, W)
         else:

@@ -31,7 +31,7 @@ import torch.nn.functional as F
 from ._lib import DST_IS_GENE, SRC_IS_GENE
 from .graph import CellGeneGraph
 from . import ops as _ops
-from .ops import linear as _linear, weighted_mean_aggregate, weighted_sum
+from .ops import linear as _linear, linear_act as _linear_act, weighted_mean_aggregate, weighted_sum
 
 
 class NodeUpdate(nn.Module):
@@ -91,7 +91,11 @@ class GNN(nn.Module):
         if h_c_compact and (want_genes or cell_rows is None):
             raise ValueError("compact cell rows can only feed the seeds' own self-loop")
         W, b = layer.fc_neigh.weight, layer.fc_neigh.bias
-        project_first = self.order == "project_first" or (self.order == "auto" and W.shape[0] <= W.shape[1])
+        # "auto": aggregate at the narrower width.  At EQUAL widths both orders aggregate the same bytes, but project-first
+        # multiplies every source row too (genes AND cells), aggregate-first only the rows this layer outputs: the last layer
+        # (cells only) then skips the [G, H] x [H, H] product - and is the reference's literal order (gnn.py:65-66).
+        project_first = self.order == "project_first" or (self.order == "auto" and (
+            W.shape[0] < W.shape[1] or (W.shape[0] == W.shape[1] and want_genes)))
         if h_g.shape[1] % 4:                               # e.g. dense_dim = 50: zero feature columns up to a multiple of 4
             extra = -h_g.shape[1] % 4
             h_g, h_c = F.pad(h_g, (0, extra)), F.pad(h_c, (0, extra))
@@ -150,13 +154,11 @@ class GNN(nn.Module):
         hc_self = h_c if (not compact or h_c_compact) else h_c[cell_rows.long()]
         z_c = weighted_mean_aggregate(g.cg, self.alpha, SRC_IS_GENE, G + 1, h_g, hc_self, row_ids=cell_rows,
                                       self_compact=compact)
-        out_c = _linear(z_c, W, b)
-        out_c = F.relu(out_c) if fuse_relu else out_c
+        out_c = _linear_act(z_c, W, b, fuse_relu)
         out_g = None
         if want_genes:
             z_g = weighted_mean_aggregate(g.gc, self.alpha, DST_IS_GENE, G, h_c, h_g)
-            out_g = _linear(z_g, W, b)
-            out_g = finish(F.relu(out_g) if fuse_relu else out_g)
+            out_g = finish(_linear_act(z_g, W, b, fuse_relu))
         return out_g, finish(out_c)
 
     def embed(self, g: CellGeneGraph, features: torch.Tensor, seeds: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -553,3 +553,14 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
 
 
 linear.widens_fp16 = True
+
+
+def linear_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], relu: bool) -> torch.Tensor:
+    """``act(x W^T + b)`` of the aggregate-first order (gnn.py:65-66: neigh -> fc_neigh -> activation).  With nothing to
+    differentiate the bias and the ReLU ride in the library GEMM's epilogue (one launch, no [n, H] elementwise pass);
+    otherwise the plain composition."""
+    if (relu and bias is not None and not torch.is_grad_enabled() and x.is_cuda and x.dim() == 2
+            and x.dtype == weight.dtype == bias.dtype and not use_wgnn_linear(x, weight)):
+        return torch._addmm_activation(bias, x, weight.t())
+    out = linear(x, weight, bias)
+    return torch.relu(out) if relu else out

@@ -15,7 +15,7 @@ from . import dist as D
 from ._lib import DST_IS_GENE, NO_ALPHA, SRC_IS_GENE
 from .gnn import GNN, _is_relu, pad_width
 from .graph import AggCsr, CellGeneGraph, _normalize_on_device, build_plan
-from .ops import agg_fwd, linear as _linear, weighted_mean_aggregate, weighted_sum
+from .ops import agg_fwd, linear as _linear, linear_act, weighted_mean_aggregate, weighted_sum
 
 
 class ShardedWgnn:
@@ -103,6 +103,14 @@ class ShardedWgnn:
             return weighted_mean_aggregate(g.cg, m.alpha, SRC_IS_GENE, G + 1, p_g, p_c if self_compact else p_c[rows.long()],
                                            bias=b, relu=relu, row_ids=rows.to(torch.int32), self_compact=True)
 
+        def cells_mean_linear(h_g, h_c, W, b, relu, rows=None, self_compact=False):
+            if rows is None:
+                z = weighted_mean_aggregate(g.cg, m.alpha, SRC_IS_GENE, G + 1, h_g, h_c)
+            else:
+                z = weighted_mean_aggregate(g.cg, m.alpha, SRC_IS_GENE, G + 1, h_g, h_c if self_compact else h_c[rows.long()],
+                                            row_ids=rows.to(torch.int32), self_compact=True)
+            return linear_act(z, W, b, relu)
+
         def genes_partial(p_c):
             if torch.is_grad_enabled() and p_c.requires_grad:
                 return weighted_sum(g.gc, p_c)
@@ -116,7 +124,7 @@ class ShardedWgnn:
             z = (a[:G].unsqueeze(1) * part + a[G] * p_g) * g.gc.inv_deg.unsqueeze(1) + b
             return F.relu(z) if relu else z
 
-        return D.LocalOps(cells_layer, genes_partial, genes_finish)
+        return D.LocalOps(cells_layer, genes_partial, genes_finish, cells_mean_linear)
 
     def _identity(self) -> AggCsr:
         """G x G identity CSR carrying the GLOBAL gene-side 1/(deg+1): lets K1's epilogue finish the all-reduced sums."""
