@@ -560,7 +560,8 @@ def linear_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
     differentiate the bias and the ReLU ride in the library GEMM's epilogue (one launch, no [n, H] elementwise pass);
     otherwise the plain composition."""
     if (relu and bias is not None and not torch.is_grad_enabled() and x.is_cuda and x.dim() == 2
-            and x.dtype == weight.dtype == bias.dtype and not use_wgnn_linear(x, weight)):
+            and x.dtype == weight.dtype == bias.dtype and not use_wgnn_linear(x, weight)
+            and hasattr(torch, "_addmm_activation")):
         return torch._addmm_activation(bias, x, weight.t())
     out = linear(x, weight, bias)
     return torch.relu(out) if relu else out
