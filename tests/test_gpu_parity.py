@@ -1628,3 +1628,32 @@ def test_tile_kernel_shared_pairs(density, D):
                 np.testing.assert_allclose(outs[(True, kb)].cpu().numpy(), outs[(False, kb)].cpu().numpy(), atol=2e-5, rtol=1e-5)
     finally:
         GR.TILE_SHARED_PAIRS = was
+
+
+def test_linear_act_fused_epilogue_and_last_layer_order():
+    """ops.linear_act: act(x W^T + b) with bias + ReLU in the library GEMM's epilogue when nothing is differentiated - against
+    fp64, with and without grad mode.  GNN "auto" order: at equal widths the LAST layer aggregates first (the reference's
+    literal order, one projection less); forcing either order gives the same logits to rounding and the oracle's."""
+    from scdeepsort_amd import ops
+    rng = np.random.default_rng(11)
+    x = rng.standard_normal((3000, 256)).astype(np.float32); W = (rng.standard_normal((256, 256)) / 16).astype(np.float32)
+    b = rng.standard_normal(256).astype(np.float32)
+    want = np.maximum(x.astype(np.float64) @ W.astype(np.float64).T + b, 0)
+    with torch.no_grad():
+        got = ops.linear_act(dev(x), dev(W), dev(b), True)
+        lin = ops.linear_act(dev(x), dev(W), dev(b), False)
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=2e-5)
+    np.testing.assert_allclose(lin.cpu().numpy(), x.astype(np.float64) @ W.astype(np.float64).T + b, atol=2e-5)
+    xg = dev(x).requires_grad_(True)
+    np.testing.assert_allclose(ops.linear_act(xg, dev(W), dev(b), True).detach().cpu().numpy(), want, atol=2e-5)
+    c = small_case(cells=500, genes=260, dim=40, hidden=32, n_layers=2, seed=21)
+    sd = O.init_params(40, 32, 5, 2, c["G"], seed=3)
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
+    want_logits = O.csr_forward(sd, O.build_csr_graph(c["expr"], c["support_mask"]), c["feats"], 2)
+    outs = {}
+    with torch.no_grad():
+        for order in ("auto", "project_first", "aggregate_first"):
+            outs[order] = make_model(sd, 40, 32, 5, 2, c["G"], order)(g, dev(c["feats"])).cpu().numpy()
+            np.testing.assert_allclose(outs[order], want_logits, atol=TOL)
+    np.testing.assert_allclose(outs["auto"], outs["project_first"], atol=2e-5)
+    np.testing.assert_allclose(outs["auto"], outs["aggregate_first"], atol=2e-5)
