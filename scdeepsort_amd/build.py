@@ -31,16 +31,114 @@ def needs_build() -> bool:
     return any(d.stat().st_mtime > LIB.stat().st_mtime for d in deps if d.exists())
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-pass-failed", "-Wno-inline-asm", f"-I{ROOT / 'include'}"]
+HAND_VGPRS = range(32, 128)         # csrc/gen_flat_asm.py HAND_VGPR_FIRST .. HAND_VGPR_LAST
+HAND_SGPRS = range(80, 96)
+
+
+class RegisterContractError(RuntimeError):
+    pass
+
+
+def flat4_resource_usage() -> dict:
+    """Compile csrc/wgnn_tiled.hip to gfx950 assembly and return, per ``agg_tiled_flat4`` instantiation, what the compiler
+    did with the register file the kernel splits by hand: the ``-Rpass-analysis=kernel-resource-usage`` remarks, the code
+    object metadata, and every compiler-emitted instruction (outside ``;;#ASMSTART`` .. ``;;#ASMEND``) that names a
+    hand-owned register (v32..v127, s80..s95)."""
+    import re
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        out = Path(td) / "wgnn_tiled.s"
+        r = subprocess.run([hipcc(), *FLAGS, "-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage",
+                            str(PKG / "csrc" / "wgnn_tiled.hip"), "-o", str(out)], capture_output=True, text=True)
+        if r.returncode:
+            raise RuntimeError(r.stderr[-4000:])
+        asm = out.read_text()
+    kernels: dict = {}
+    cur = None
+    for line in r.stderr.splitlines():                       # remark blocks: "Function Name: <sym>" then one remark per figure
+        m = re.search(r"remark: +(?:Function )?Name: (\S+)", line)
+        if m:
+            cur = kernels.setdefault(m.group(1), {"remarks": {}}) if "agg_tiled_flat4" in m.group(1) else None
+            continue
+        m = re.search(r"remark: +([A-Za-z ]+?)(?: \[[^\]]*\])?: (\S+)", line)
+        if m and cur is not None:
+            cur["remarks"][m.group(1).strip()] = m.group(2)
+    for name, rec in kernels.items():
+        m = re.search(r"^\s*\.name:\s+%s\s*$" % re.escape(name), asm, re.M)
+        md = asm[asm.rfind("- .agpr_count", 0, m.start()) if m else 0: m.start() if m else 0] if m else ""
+        # metadata entries of one kernel sit in one YAML map: take the fields around .name
+        blk_start = asm.rfind("  - .", 0, m.start())
+        blk_end = asm.find("\n  - .", m.end())
+        blk = asm[blk_start: blk_end if blk_end > 0 else len(asm)]
+        rec["metadata"] = {k: int(v) for k, v in re.findall(r"\.(sgpr_spill_count|vgpr_spill_count|private_segment_fixed_size|"
+                                                            r"vgpr_count|sgpr_count|agpr_count):\s+(\d+)", blk)}
+        body_start = asm.index(f"\n{name}:")
+        body = asm[body_start: asm.index(".Lfunc_end", body_start)]
+        bad, in_asm = [], False
+        for ln in body.splitlines():
+            t = ln.strip()
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+            elif t.startswith(";;#ASMEND"):
+                in_asm = False
+            elif not in_asm and t and not t.startswith((";", ".", "//")):
+                code = t.split(";")[0]
+                regs = [("v", int(a), int(b or a)) for a, b in re.findall(r"\bv\[?(\d+)(?::(\d+))?\]?", code)]
+                regs += [("s", int(a), int(b or a)) for a, b in re.findall(r"\bs\[?(\d+)(?::(\d+))?\]?", code)]
+                for kind, lo, hi in regs:
+                    own = HAND_VGPRS if kind == "v" else HAND_SGPRS
+                    if hi >= own.start and lo < own.stop:
+                        # reads of chunk / segment / accumulator registers that the SOURCE asks for are inside asm
+                        # statements; anything here was emitted by the compiler on its own
+                        bad.append(code)
+                        break
+        rec["compiler_touches_hand_registers"] = bad
+    return kernels
+
+
+def audit_flat4(usage: dict | None = None) -> dict:
+    """Build-time guard of agg_tiled_flat4's hand-allocated register file: raises RegisterContractError when
+    any instantiation spills, uses scratch, does not get exactly 128 VGPRs, or when the compiler itself touches a
+    hand-owned register."""
+    usage = flat4_resource_usage() if usage is None else usage
+    if len(usage) < 6:
+        raise RegisterContractError(f"expected 6 agg_tiled_flat4 instantiations, found {sorted(usage)}")
+    for name, rec in usage.items():
+        md, rm = rec["metadata"], rec["remarks"]
+        problems = []
+        if md.get("sgpr_spill_count", -1) != 0 or md.get("vgpr_spill_count", -1) != 0:
+            problems.append(f"spills: {md}")
+        if md.get("private_segment_fixed_size", -1) != 0:
+            problems.append(f"scratch: {md}")
+        if md.get("vgpr_count") != 128:
+            problems.append(f"vgpr_count {md.get('vgpr_count')} != 128 (4 waves per SIMD)")
+        if rm.get("SGPRs Spill") != "0" or rm.get("VGPRs Spill") != "0" or rm.get("ScratchSize") not in ("0", None) or \
+                rm.get("VGPRs") != "128":
+            problems.append(f"resource remarks: {rm}")
+        if rec["compiler_touches_hand_registers"]:
+            problems.append("compiler-emitted instructions name hand-owned registers: "
+                            + " | ".join(rec["compiler_touches_hand_registers"][:5]))
+        if problems:
+            raise RegisterContractError(f"{name}: " + "; ".join(problems))
+    return usage
+
+
+def build(force: bool = False, verbose: bool = False, audit: bool = True) -> Path:
     if not force and not needs_build():
         return LIB
     import runpy
     runpy.run_path(str(GEN))["main"](str(PKG / "csrc" / "wgnn_flat_asm.inc"))
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           "-Wno-pass-failed", "-Wno-inline-asm", f"-I{ROOT / 'include'}", *map(str, SRC), "-o", str(LIB)]
+    cmd = [hipcc(), *FLAGS, "-shared", "-fPIC", *map(str, SRC), "-o", str(LIB)]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
+    if audit:                                                # the hand-split register file of agg_tiled_flat4 is a build-time contract
+        try:
+            audit_flat4()
+        except RegisterContractError:
+            LIB.unlink(missing_ok=True)                      # never leave a library behind that violates it
+            raise
     return LIB
 
 

@@ -41,6 +41,9 @@ import os
 import sys
 
 N_PAIRS = 32
+# the hand-owned part of the register file (the compiler gets v[0:31] / s[0:79]: amdgpu_num_vgpr / amdgpu_num_sgpr)
+HAND_VGPR_FIRST, HAND_VGPR_LAST = 32, 127
+HAND_SGPR_FIRST, HAND_SGPR_LAST = 80, 95
 ABLATE = set(filter(None, os.environ.get("WGNN_GEN_ABLATE", "").split(",")))   # timing experiments only (wrong results)
 DEPTH = int(os.environ.get("WGNN_GEN_DEPTH", "1"))      # LDS reads are issued DEPTH steps ahead of their FMAs
 XREGS = [(48, 52), (56, 60), (96, 100)]    # staging buffers, first regs of entry 0 / entry 1 (third: DEPTH=2 experiment)
@@ -252,6 +255,10 @@ def main(path):
     body = "".join(f'    "{ln}\\n\\t"\n' for ln in lines)
     with open(path, "w") as f:
         f.write("// GENERATED by gen_flat_asm.py - do not edit.  See that file for the register contract.\n")
+        # every register the hand-written statements of agg_tiled_flat4 own, spelled out for their clobber lists (a clobber
+        # list takes single registers, not ranges: naming only the end points would leave the ones in between "free")
+        f.write("#define WGNN_HAND_VGPRS " + ", ".join(f'"v{i}"' for i in range(HAND_VGPR_FIRST, HAND_VGPR_LAST + 1)) + "\n")
+        f.write("#define WGNN_HAND_SGPRS " + ", ".join(f'"s{i}"' for i in range(HAND_SGPR_FIRST, HAND_SGPR_LAST + 1)) + "\n")
         f.write("#define WGNN_FLAT4_ASM \\\n")
         f.write("".join(f'    "{ln}\\n\\t" \\\n' for ln in lines))
         f.write('    ""\n')

@@ -171,14 +171,21 @@ __global__ void __launch_bounds__(kTW * 64) agg_tiled(const KArgs a, const TArgs
     }
 }
 
-#define WGNN_CLOB "m0", "memory", "v48", "v63", "v64", "v127"
+// clobber list of a hand-written statement: EVERY register of the hand-owned file by name (gen_flat_asm.py spells them out)
+#define WGNN_CLOB "m0", "memory", "scc", WGNN_HAND_VGPRS, WGNN_HAND_SGPRS
 
 // ---------------------------------------------------------------------------------------------
 // agg_tiled_flat4 - the D == 256 specialisation.  Same tile / block structure as agg_tiled, but
-//  * the register file is split: the compiler may allocate v[0:31] / s[0:79] only (amdgpu_num_vgpr / amdgpu_num_sgpr);
-//    v[64:127] are the wave's 16 x float4 accumulators, v[48:63] two LDS staging buffers, v[32:45] chunk / segment /
+//  * the register file is split: the compiler may allocate v[0:31] / s[0:79] only.  amdgpu_num_vgpr(16), not 32: on
+//    gfx90a+ the attribute counts the unified VGPR + AGPR file and the allocator takes up to TWICE the figure as plain
+//    VGPRs (probe kernel: 16 -> v0..v31, 24 -> v0..v47, 32 -> v0..v63) - rounds 1-3 declared 32 and the compiler in fact
+//    owned v0..v63, overlapping the hand-owned registers (its epilogue used v32..v35; harmless there, unguarded anywhere);
+//    v[64:127] are the wave's 16 x float4 accumulators, v[48:63] two LDS staging buffers, v[32:46] chunk / segment /
 //    weight / address registers, s[80:95] per-entry scalars.  They are touched exclusively by literal-register inline
-//    asm, so the compiler never copies or spills them;
+//    asm, so the compiler never copies or spills them.  The contract is ENFORCED at build time (build.audit_flat4:
+//    0 spilled SGPRs / VGPRs, no scratch, and no compiler-emitted instruction outside ;;#ASMSTART .. ;;#ASMEND names
+//    v32..v127 or s80..s95 - a spill lane parked in the hand-owned file would corrupt results silently) and every
+//    hand-written statement names the whole hand-owned file in its clobber list;
 //  * the destination row of an entry is a run-time value: the accumulators are addressed through GPR-index mode
 //    (s_set_gpr_idx_on: VGPR number += M0[7:0]), so there is no per-row control flow;
 //  * the per-entry loop is the generated straight-line pipeline of gen_flat_asm.py (4 VALU per entry);
@@ -199,7 +206,7 @@ template <int SET> __device__ __forceinline__ int2 chunk_get() {
 }
 
 template <typename TOut, int EPI, bool DBG>
-__global__ void __launch_bounds__(kTW * 64) __attribute__((amdgpu_num_vgpr(32), amdgpu_num_sgpr(80)))
+__global__ void __launch_bounds__(kTW * 64) __attribute__((amdgpu_num_vgpr(16), amdgpu_num_sgpr(80)))
 agg_tiled_flat4(const KArgs a, const TArgs t) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int row_bytes = 1024;                      // LDS row stride: fixed, so that {LDS row address | 4*slot} packs into one dword
@@ -305,9 +312,7 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
         asm volatile("ds_write_b32 %[wa], %[wv]\n\t" WGNN_FLAT4_ASM
                      ::[pk] "v"(pk), [wa] "v"(wlane_addr), [wv] "v"(wv), [wb] "v"(wstrip_addr), [lb] "v"(lane16),
                        [mk] "v"(row_mask), [m] "s"(m), [sw] "s"(sw)
-                     : "m0", "memory", "scc", "v40", "v41", "v42", "v43", "v44", "v45", "v48", "v63", "v64", "v127",
-                       "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93",
-                       "s94", "s95");
+                     : WGNN_CLOB);
     };
     auto compute = [&](auto cur_set, int cs, int ce0, int buf_addr) {
         constexpr int CUR = decltype(cur_set)::value;
@@ -386,6 +391,16 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
         }
     }
 
+    // The epilogue re-reads its arguments from the kernarg segment through a pointer the optimiser cannot see through:
+    // otherwise every epilogue-only field of `a` (output / self / bias / alpha / inv_deg pointers, strides, partial-sum base)
+    // is loaded in the prologue and kept in SGPRs across the whole block loop, which overflows the s[0:79] the compiler
+    // owns here and spills into VGPR lanes (round 3: 3 .. 20 spilled SGPRs per instantiation, parked in a VGPR outside
+    // the declared budget).  `a` is the kernel's first parameter, i.e. offset 0 of the kernarg segment.
+    typedef const __attribute__((address_space(4))) KArgs* kargs_cptr_t;
+    kargs_cptr_t a_late = (kargs_cptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(a_late));
+    {                                                    // ---- epilogue scope
+    const KArgs a = *(const KArgs*)a_late;                             // shadows the parameter from here on (dead fields are never loaded)
     const int4* __restrict__ items = t.tile_items + (size_t)tile * kTileRows + wave * kRPW;
     auto acc_row = [&](int i) {                          // accumulator row i of this wave -> compiler registers
         float4 v;
@@ -404,31 +419,48 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
             const bool lane_on = lane * 4 < a.D;
             const bool no_mean = a.flags & WGNN_FLAG_NO_MEAN, relu = a.flags & WGNN_FLAG_RELU;
             const bool has_self = !(a.flags & WGNN_FLAG_NO_SELF) && a.self != nullptr;
-            const float a_self = has_self ? (a.mode == WGNN_NO_ALPHA ? 1.0f : a.alpha[a.self_idx]) : 0.0f;
-            float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.bias && lane_on) bias4 = ld4(a.bias + lane * 4);
+            // per-row factors (inv_deg, alpha: inputs nobody writes during the launch) come through the scalar cache like
+            // the item words: the rows are wave-uniform, and as SGPR values they cost no vector registers - the compiler
+            // owns v[0:31] only and this epilogue is the place where it needs them all
+            typedef const __attribute__((address_space(4))) float* cfptr_t;
+            cfptr_t s_alpha = (cfptr_t)a.alpha, s_inv_deg = (cfptr_t)a.inv_deg;
+            const float a_self = has_self ? (a.mode == WGNN_NO_ALPHA ? 1.0f : s_alpha[a.self_idx]) : 0.0f;
             const float* selfp = reinterpret_cast<const float*>(a.self);
             float* outp = reinterpret_cast<float*>(a.out);
             for (int i0 = 0; i0 < kRPW; i0 += 2) {
                 int slot[2], pslot[2];
                 float4 sf[2];
                 float invd[2], rs[2];
+                // the lane's byte offset inside a row, opaque per trip: every access below is then "uniform row base
+                // (SGPR pair) + 32-bit lane offset" - left visible, the offset is folded into each of the four base
+                // pointers ahead of the loop, i.e. four 64-bit per-lane addresses (8 VGPRs) held across it
+                unsigned lo = (unsigned)lane * 16u;
+                asm volatile("" : "+v"(lo));
+                typedef __attribute__((address_space(1))) float4* gf4_t;                          // global_load / global_store, saddr form
+                auto at = [&](const float* base, size_t row, long ld) {
+                    __attribute__((address_space(1))) char* rb =                                  // wave-uniform row base
+                        (__attribute__((address_space(1))) char*)const_cast<float*>(base + row * ld);
+                    asm volatile("" : "+s"(rb));                                                  // ... kept in an SGPR pair
+                    return (gf4_t)(rb + lo);
+                };
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     slot[k] = sitems[4 * (i0 + k)]; pslot[k] = sitems[4 * (i0 + k) + 3];
                 }
+                float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);     // requested per trip, together with the self rows (1 KiB, L1-resident)
+                if (a.bias && lane_on) bias4 = *at(a.bias, 0, 0);
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     sf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (slot[k] >= 0 && pslot[k] < 0 && has_self && lane_on)
-                        sf[k] = ld4(selfp + (size_t)slot[k] * a.ld_self + lane * 4);
+                        sf[k] = *at(selfp, slot[k], a.ld_self);
                 }
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     invd[k] = 1.0f; rs[k] = 1.0f;
                     if (slot[k] >= 0 && pslot[k] < 0) {
-                        if (!no_mean) invd[k] = a.inv_deg ? a.inv_deg[slot[k]] : 1.0f / (row_degree(a, slot[k]) + 1.0f);
-                        rs[k] = invd[k] * (a.mode == WGNN_DST_IS_GENE ? a.alpha[slot[k]] : 1.0f);
+                        if (!no_mean) invd[k] = a.inv_deg ? s_inv_deg[slot[k]] : 1.0f / (row_degree(a, slot[k]) + 1.0f);
+                        rs[k] = invd[k] * (a.mode == WGNN_DST_IS_GENE ? s_alpha[slot[k]] : 1.0f);
                     }
                 }
 #pragma unroll
@@ -436,15 +468,15 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
                     if (slot[k] < 0) continue;
                     float4 o = acc_row(i0 + k);
                     if (pslot[k] >= 0) {
-                        if (lane_on) st4(a.partials + (size_t)pslot[k] * a.D + lane * 4, o);
+                        if (lane_on) *at(a.partials, pslot[k], a.D) = o;
                         continue;
                     }
-                    if (a.aux1 && lane_on) st4(a.aux1 + (size_t)slot[k] * a.D + lane * 4, o);      // raw neighbour sum
+                    if (a.aux1 && lane_on) *at(a.aux1, slot[k], a.D) = o;                      // raw neighbour sum
                     o.x *= rs[k]; o.y *= rs[k]; o.z *= rs[k]; o.w *= rs[k];
                     if (has_self) fma4(o, invd[k] * a_self, sf[k]);
                     if (a.bias) { o.x += bias4.x; o.y += bias4.y; o.z += bias4.z; o.w += bias4.w; }
                     if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-                    if (lane_on) st4(outp + (size_t)slot[k] * a.ld_out + lane * 4, o);
+                    if (lane_on) *at(outp, slot[k], a.ld_out) = o;
                 }
             }
             return;
@@ -462,6 +494,7 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
             epilogue<64, 1, float, TOut, EPI>(a, one, slot, lane, true);
         }
     }
+    }                                                    // ---- epilogue scope
 }
 
 // LDS bytes of one launch: the flat kernel keeps 1 KiB LDS rows whatever D is (+ the per-wave weight strips)

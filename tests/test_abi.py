@@ -167,3 +167,43 @@ def test_workspace_query():
     assert (pb.value, sb.value) == (0, 0)
     assert lib.wgnn_agg_workspace_bytes(1, 1, 6, 0, 0, C.addressof(pb), C.addressof(sb)) == -2      # WGNN_ERR_ALIGNMENT
     assert lib.wgnn_agg_workspace_bytes(-1, 1, 8, 0, 0, C.addressof(pb), C.addressof(sb)) == -1     # WGNN_ERR_BAD_ARG
+
+
+def test_flat4_register_contract_is_enforced_at_build_time():
+    """agg_tiled_flat4 splits the register file by hand (compiler v[0:31] / s[0:79]; accumulators, staging and
+    chunk registers above).  The build audits every instantiation: `-Rpass-analysis=kernel-resource-usage` says VGPRs 128,
+    scratch 0, spills 0; the code-object metadata agrees; and no compiler-emitted instruction (outside the inline-asm
+    regions) names v32..v127 / s80..s95 - round 3's build parked 3-20 spilled SGPRs in a VGPR of the hand-owned file."""
+    from scdeepsort_amd import build as B
+    usage = B.flat4_resource_usage()
+    assert len(usage) == 6 and all("agg_tiled_flat4" in k for k in usage)           # 3 epilogues x {production, ablation}
+    for name, rec in usage.items():
+        rm, md = rec["remarks"], rec["metadata"]
+        assert rm["VGPRs"] == "128" and rm["ScratchSize"] == "0", (name, rm)
+        assert rm["SGPRs Spill"] == "0" and rm["VGPRs Spill"] == "0" and rm["Occupancy"] == "4", (name, rm)
+        assert md["sgpr_spill_count"] == 0 and md["vgpr_spill_count"] == 0 and md["private_segment_fixed_size"] == 0, (name, md)
+        assert rec["compiler_touches_hand_registers"] == [], (name, rec["compiler_touches_hand_registers"][:5])
+    B.audit_flat4(usage)
+    # the audit does reject a violation: a fake record with one spilled SGPR / a compiler write into the accumulators
+    import copy
+    bad = copy.deepcopy(usage)
+    next(iter(bad.values()))["metadata"]["sgpr_spill_count"] = 1
+    with pytest.raises(B.RegisterContractError):
+        B.audit_flat4(bad)
+    bad = copy.deepcopy(usage)
+    next(iter(bad.values()))["compiler_touches_hand_registers"] = ["v_writelane_b32 v47, s8, 0"]
+    with pytest.raises(B.RegisterContractError):
+        B.audit_flat4(bad)
+
+
+def test_hand_written_statements_name_every_owned_register():
+    """The clobber lists of the flat kernel's asm statements spell out v32..v127 / s80..s95 one by one (a clobber list takes
+    single registers: `"v48", "v63"` names two registers, not a range)."""
+    inc = (ROOT / "scdeepsort_amd" / "csrc" / "wgnn_flat_asm.inc").read_text()
+    vl = next(l for l in inc.splitlines() if l.startswith("#define WGNN_HAND_VGPRS"))
+    sl = next(l for l in inc.splitlines() if l.startswith("#define WGNN_HAND_SGPRS"))
+    assert [f'"v{i}"' for i in range(32, 128)] == [t.strip() for t in vl.split("WGNN_HAND_VGPRS", 1)[1].split(",")]
+    assert [f'"s{i}"' for i in range(80, 96)] == [t.strip() for t in sl.split("WGNN_HAND_SGPRS", 1)[1].split(",")]
+    src = (ROOT / "scdeepsort_amd" / "csrc" / "wgnn_tiled.hip").read_text()
+    assert '#define WGNN_CLOB "m0", "memory", "scc", WGNN_HAND_VGPRS, WGNN_HAND_SGPRS' in src
+    assert "amdgpu_num_vgpr(16), amdgpu_num_sgpr(80)" in src
