@@ -27,8 +27,8 @@ from .graph import CellGeneGraph
 def _device(gpu_id: int) -> torch.device:
     if not torch.cuda.is_available():
         raise WgnnError("the MI355X path needs a GPU (gpu_id=-1 meant CPU in the reference; there is no CPU fallback here)")
-    # the caller's current device is left alone: every C-ABI call runs under ``_lib.call``'s device guard and every tensor
-    # below is created on ``dev`` explicitly
+    # ``fit`` / ``_predict`` run under ``torch.cuda.device(dev)`` (restored on exit): C-ABI calls are guarded per call by
+    # ``_lib.call``, but hipGraph capture (GraphedTrainStep / GraphedForward) opens its stream on the CURRENT device
     return torch.device("cuda", max(gpu_id, 0))
 
 
@@ -148,6 +148,12 @@ class DeepSortClassifier:
     # ---------------------------------------------------------------------------------------------
     def fit(self, files: Sequence[Tuple[str, str]], save_path=None):
         """``files`` = list of (data_file, celltype_file) (docs/api.rst:89-95)."""
+        # everything below - allocations, Adam state, hipGraph capture streams (``torch.cuda.graph`` opens its capture stream
+        # on the CURRENT device) - must see ``gpu_id``'s device as current; the caller's device is restored on exit
+        with torch.cuda.device(_device(self.gpu_id)):
+            return self._fit(files, save_path)
+
+    def _fit(self, files: Sequence[Tuple[str, str]], save_path=None):
         dev = _device(self.gpu_id)
         if self.random_seed is not None:
             np.random.seed(self.random_seed); torch.manual_seed(self.random_seed)
@@ -270,6 +276,13 @@ class DeepSortPredictor:
 
 def _predict(species, tissue, input_file, model_path: Path, save_path, unsure_rate, file_type, dense_dim, hidden_dim,
              gpu_id, threshold, seed) -> pd.DataFrame:
+    with torch.cuda.device(_device(gpu_id)):                 # current device = gpu_id's for the call, restored on exit
+        return _predict_on(species, tissue, input_file, model_path, save_path, unsure_rate, file_type, dense_dim, hidden_dim,
+                           gpu_id, threshold, seed)
+
+
+def _predict_on(species, tissue, input_file, model_path: Path, save_path, unsure_rate, file_type, dense_dim, hidden_dim,
+                gpu_id, threshold, seed) -> pd.DataFrame:
     dev = _device(gpu_id)
     id2gene = [l.strip() for l in (model_path / f"{tissue}_genes.txt").read_text().splitlines() if l.strip()]
     id2label = [l.strip() for l in (model_path / f"{tissue}_cell_type.txt").read_text().splitlines() if l.strip()]

@@ -35,9 +35,10 @@ class GraphedForward:
             for _ in range(max(1, warmup)):
                 self.logits = model(graph, self.features, seeds=self.seeds)
         torch.cuda.current_stream(graph.device).wait_stream(side)
-        self._g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._g), torch.no_grad():
-            self.logits = model(graph, self.features, seeds=self.seeds)
+        with torch.cuda.device(graph.device):                   # the capture stream is opened on the CURRENT device
+            self._g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._g), torch.no_grad():
+                self.logits = model(graph, self.features, seeds=self.seeds)
 
     def __call__(self, features: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Replays the captured forward (on new ``features`` of the same shape if given).  The returned tensor is the
@@ -76,9 +77,10 @@ class GraphedTrainStep:
             return self._eager(batch)
         if self._g is None:
             self._ids = batch.clone()
-            self._g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._g):
-                self._loss = self.step_fn(self._ids)
+            with torch.cuda.device(self.device):                 # capture on the device that owns the model, whatever is current
+                self._g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._g):
+                    self._loss = self.step_fn(self._ids)
         else:
             self._ids.copy_(batch)
         self._g.replay()

@@ -453,6 +453,8 @@ def use_wgnn_linear(x: torch.Tensor, weight: torch.Tensor, dual: bool = False) -
     if WGNN_LINEAR == "never" or not x.is_cuda or x.dim() != 2 or x.shape[1] % 4 or torch.is_grad_enabled() and (
             x.requires_grad or weight.requires_grad):
         return False
+    if weight.dtype != torch.float32:          # wgnn_linear_fwd computes and returns fp32: a .half() / .bfloat16() model keeps
+        return False                           # F.linear's "output in the parameter dtype"
     if dual:
         return WGNN_LINEAR_DUAL
     if WGNN_LINEAR == "always":
@@ -562,6 +564,9 @@ def linear_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
     if (relu and bias is not None and not torch.is_grad_enabled() and x.is_cuda and x.dim() == 2
             and x.dtype == weight.dtype == bias.dtype and not use_wgnn_linear(x, weight)
             and hasattr(torch, "_addmm_activation")):
-        return torch._addmm_activation(bias, x, weight.t())
+        try:                                       # a private torch entry point: any change of its contract falls back to
+            return torch._addmm_activation(bias, x, weight.t())      # the plain composition below
+        except (RuntimeError, TypeError):
+            pass
     out = linear(x, weight, bias)
     return torch.relu(out) if relu else out

@@ -183,6 +183,14 @@ class ShardedWgnn:
         if self.world == 1:
             return m.linear(m.embed(self.graph, (feats_g, feats_c_local)))
         self.wait_gather()
+        if gather_logits and D.comm_active() and (self.shard_sizes is None or len(self.shard_sizes) != D.world()[1]):
+            # an engine constructed directly (not through ``build``, which exchanges the sizes): one exchange, cached -
+            # the per-forward concat then needs no size exchange / host read (``dist.sharded_forward`` raises without them)
+            import torch.distributed as tdist
+            mine = torch.tensor([self.graph.num_cells], dtype=torch.long, device=self.graph.device)
+            every = [torch.zeros_like(mine) for _ in range(D.world()[1])]
+            tdist.all_gather(every, mine)
+            self.shard_sizes = [int(t.item()) for t in every]
         res = D.sharded_forward(self._weights(), None, feats_g, feats_c_local, self._ops(), m.n_layers, gather_logits,
                                 self.shard_sizes, async_gather, self.dropout_masks(feats_g, feats_c_local), self.relu, _linear)
         if async_gather:
