@@ -252,12 +252,22 @@ def main():
     # launch-bound configs (cfg2: ~25 launches of a few us each): the same forward captured once and replayed as one hipGraph
     # launch per step (scdeepsort_amd.graphed.GraphedForward); per-launch HIP events cannot be recorded inside a replay, so
     # the roofline's per-kernel durations come from a short eager pass of the same forward outside the timed region
-    graphed = world == 1 and (args.graphed == "on" or (args.graphed == "auto" and cfg.cells * cfg.genes <= 100_000_000))
-    step_fn = None
-    if graphed:
+    # N > 1: a rank's shard of the strong-scaling job is launch-bound as well (12.5k cells per rank at N = 8: ~15 short launches
+    # and two collectives per forward) - the whole sharded forward INCLUDING the RCCL collectives replays as one hipGraph
+    # (graphed.GraphedShardedForward; with a host-side backend such as gloo: graph segments around eager collectives)
+    graphed = (world == 1 and (args.graphed == "on" or (args.graphed == "auto" and cfg.cells * cfg.genes <= 100_000_000))) \
+        or (world > 1 and args.graphed != "off")
+    step_fn, launch_desc = None, "eager"
+    if graphed and world == 1:
         from scdeepsort_amd.graphed import GraphedForward
         gf = GraphedForward(model, engine.graph, torch.cat([feats_g, feats_c]))
+        step_fn, launch_desc = (lambda: gf()), "hipGraph replay (1 launch per step)"
+    elif graphed:
+        from scdeepsort_amd.graphed import GraphedShardedForward
+        gf = GraphedShardedForward(engine, feats_g, feats_c)
         step_fn = lambda: gf()
+        launch_desc = ("hipGraph replay (1 launch per step, RCCL collectives captured)" if gf.mode == "whole" else
+                       f"hipGraph replay in {gf.n_graphs} segments around {gf.n_eager_collectives} host-side collectives ({backend})")
     dt, dt_local, prof, out = timed_steps(engine, feats_g, feats_c, args.steps, args.warmup, world, dev, step=step_fn)
     assert torch.isfinite(out).all()
     eager_ms = None
@@ -396,7 +406,7 @@ def main():
                            "cells_total": total_cells, "cells_this_rank": C,
                            "nnz_per_gpu": per_gpu[0]["nnz"] if per_gpu else roofline["passes"][0]["nnz"],
                            "parallelism": f"cell-shard x{world}", "setup_s": round(t_setup, 1), "communicator": comm,
-                           "step_launch": "hipGraph replay (1 launch per step)" if graphed else "eager", "eager_ms_per_step": eager_ms,
+                           "step_launch": launch_desc, "eager_ms_per_step": eager_ms,
                            "sharded_vs_unsharded": self_check},
                 "roofline": roofline, "cpu_baseline": cpu, "sustained": sustained, "weak_scaling": weak}
         print(json.dumps(line))

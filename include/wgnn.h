@@ -42,13 +42,15 @@
 extern "C" {
 #endif
 
-#define WGNN_VERSION 201           /* 0.2.x - INCOMPATIBLE with 0.1.x binders: `neigh_sum` was inserted before `n_out` in
+#define WGNN_VERSION 202           /* 0.2.x - INCOMPATIBLE with 0.1.x binders: `neigh_sum` was inserted before `n_out` in
                                       wgnn_agg_fwd / wgnn_agg_fwd_tiled (0.1.1, should have been a major bump then - a 0.1.0
                                       caller would pass n_out in a pointer slot); 0.2.0 adds int64 row pointers
                                       (WGNN_FLAG_ROWPTR_I64, wgnn_normalize_rows_i64), WGNN_FLAG_SRC_PRESCALED and
                                       wgnn_linear_fwd_ex.  Binders must check wgnn_version() / 100 == 2.
                                       0.2.1: tile-plan entries may mark shared pairs (see wgnn_agg_fwd_tiled); a 0.2.0
-                                      library would misread the marks, so a plan that carries them needs >= 201. */
+                                      library would misread the marks, so a plan that carries them needs >= 201.
+                                      0.2.2: WGNN_FLAG_OUT_SCALE_ALPHA (an older library ignores the bit: callers that set it
+                                      need >= 202). */
 
 /* error codes */
 #define WGNN_OK                 0
@@ -81,6 +83,12 @@ extern "C" {
                                      < 2^31 non-zeros per GPU (see wgnn_plan_build_host_i64)                    */
 #define WGNN_FLAG_SRC_PRESCALED 32u /* wgnn_agg_fwd_tiled, WGNN_SRC_IS_GENE: h_src already holds alpha[s]*h[s] (written by
                                      wgnn_linear_fwd_ex's scaled output); no scale pass, src_scratch may be NULL */
+
+#define WGNN_FLAG_OUT_SCALE_ALPHA 64u /* wgnn_agg_fwd / wgnn_agg_fwd_tiled, WGNN_DST_IS_GENE (rows are genes): the finished row
+                                     (after mean / self-loop / bias / ReLU) is multiplied by alpha[row] once more, i.e. the
+                                     output is the NEXT layer's alpha-folded gene table, (h*alpha) of gnn.py:54, ready for
+                                     WGNN_FLAG_SRC_PRESCALED - used when nothing else reads the unscaled gene rows (the
+                                     layer below a cells-only last layer).  Forward entries only                */
 
 int         wgnn_version(void);
 const char* wgnn_last_error_string(int code);

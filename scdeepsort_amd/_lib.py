@@ -14,9 +14,9 @@ LIB_PATH = Path(__file__).resolve().parent / "libwgnn_hip.so"
 # error codes / enums (mirror include/wgnn.h)
 SRC_IS_GENE, DST_IS_GENE, NO_ALPHA = 0, 1, 2
 F32, F16 = 0, 1
-FLAG_RELU, FLAG_NO_MEAN, FLAG_NO_SELF, FLAG_SELF_COMPACT, FLAG_ROWPTR_I64, FLAG_SRC_PRESCALED = 1, 2, 4, 8, 16, 32
+FLAG_RELU, FLAG_NO_MEAN, FLAG_NO_SELF, FLAG_SELF_COMPACT, FLAG_ROWPTR_I64, FLAG_SRC_PRESCALED, FLAG_OUT_SCALE_ALPHA = 1, 2, 4, 8, 16, 32, 64
 ABI_MAJOR = 2                      # include/wgnn.h WGNN_VERSION / 100
-ABI_MIN = 201                      # shared-pair marks in tile-plan entries (graph._pair_segment_entries) need 0.2.1
+ABI_MIN = 202                      # 0.2.1: shared-pair marks in tile-plan entries; 0.2.2: WGNN_FLAG_OUT_SCALE_ALPHA (gnn.GNN sets it)
 
 _vp, _i32, _i64, _u32, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_int
 

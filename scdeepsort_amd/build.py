@@ -33,7 +33,6 @@ def needs_build() -> bool:
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-pass-failed", "-Wno-inline-asm", f"-I{ROOT / 'include'}"]
 HAND_VGPRS = range(32, 128)         # csrc/gen_flat_asm.py HAND_VGPR_FIRST .. HAND_VGPR_LAST
-HAND_SGPRS = range(80, 96)
 
 
 class RegisterContractError(RuntimeError):
@@ -44,7 +43,8 @@ def flat4_resource_usage() -> dict:
     """Compile csrc/wgnn_tiled.hip to gfx950 assembly and return, per ``agg_tiled_flat4`` instantiation, what the compiler
     did with the register file the kernel splits by hand: the ``-Rpass-analysis=kernel-resource-usage`` remarks, the code
     object metadata, and every compiler-emitted instruction (outside ``;;#ASMSTART`` .. ``;;#ASMEND``) that names a
-    hand-owned register (v32..v127, s80..s95)."""
+    hand-owned VECTOR register (v32..v127: they carry state across statements; the literal scalar registers s80..s95 are
+    statement-local and declared as clobbers, the compiler may use them in between)."""
     import re
     import tempfile
     with tempfile.TemporaryDirectory() as td:
@@ -85,10 +85,8 @@ def flat4_resource_usage() -> dict:
             elif not in_asm and t and not t.startswith((";", ".", "//")):
                 code = t.split(";")[0]
                 regs = [("v", int(a), int(b or a)) for a, b in re.findall(r"\bv\[?(\d+)(?::(\d+))?\]?", code)]
-                regs += [("s", int(a), int(b or a)) for a, b in re.findall(r"\bs\[?(\d+)(?::(\d+))?\]?", code)]
                 for kind, lo, hi in regs:
-                    own = HAND_VGPRS if kind == "v" else HAND_SGPRS
-                    if hi >= own.start and lo < own.stop:
+                    if hi >= HAND_VGPRS.start and lo < HAND_VGPRS.stop:
                         # reads of chunk / segment / accumulator registers that the SOURCE asks for are inside asm
                         # statements; anything here was emitted by the compiler on its own
                         bad.append(code)

@@ -82,6 +82,7 @@ __device__ __forceinline__ void epilogue(const KArgs& a, float4 (&acc)[NV], int 
         const float rs = invd * (a.mode == WGNN_DST_IS_GENE ? a.alpha[r] : 1.0f);
         const bool has_self = !(a.flags & WGNN_FLAG_NO_SELF) && a.self != nullptr;
         const float sc = has_self ? invd * (a.mode == WGNN_NO_ALPHA ? 1.0f : a.alpha[a.self_idx]) : 0.0f;
+        const float post = (a.flags & WGNN_FLAG_OUT_SCALE_ALPHA) && a.mode == WGNN_DST_IS_GENE ? a.alpha[r] : 1.0f;
         const TIn* selfp = reinterpret_cast<const TIn*>(a.self) +
                            (size_t)((a.flags & WGNN_FLAG_SELF_COMPACT) ? slot : r) * a.ld_self;
         TOut* outp = reinterpret_cast<TOut*>(a.out) + (size_t)slot * a.ld_out;
@@ -97,6 +98,7 @@ __device__ __forceinline__ void epilogue(const KArgs& a, float4 (&acc)[NV], int 
                 if (a.flags & WGNN_FLAG_RELU) {
                     o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f);
                 }
+                if (a.flags & WGNN_FLAG_OUT_SCALE_ALPHA) { o.x *= post; o.y *= post; o.z *= post; o.w *= post; }
                 st4(outp + c0, o);
             }
         }

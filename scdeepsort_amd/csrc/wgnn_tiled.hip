@@ -177,16 +177,19 @@ __global__ void __launch_bounds__(kTW * 64) agg_tiled(const KArgs a, const TArgs
 
 // ---------------------------------------------------------------------------------------------
 // agg_tiled_flat4 - the D == 256 specialisation.  Same tile / block structure as agg_tiled, but
-//  * the register file is split: the compiler may allocate v[0:31] / s[0:79] only.  amdgpu_num_vgpr(16), not 32: on
+//  * the VECTOR register file is split: the compiler may allocate v[0:31] only.  amdgpu_num_vgpr(16), not 32: on
 //    gfx90a+ the attribute counts the unified VGPR + AGPR file and the allocator takes up to TWICE the figure as plain
 //    VGPRs (probe kernel: 16 -> v0..v31, 24 -> v0..v47, 32 -> v0..v63) - rounds 1-3 declared 32 and the compiler in fact
 //    owned v0..v63, overlapping the hand-owned registers (its epilogue used v32..v35; harmless there, unguarded anywhere);
 //    v[64:127] are the wave's 16 x float4 accumulators, v[48:63] two LDS staging buffers, v[32:46] chunk / segment /
-//    weight / address registers, s[80:95] per-entry scalars.  They are touched exclusively by literal-register inline
-//    asm, so the compiler never copies or spills them.  The contract is ENFORCED at build time (build.audit_flat4:
-//    0 spilled SGPRs / VGPRs, no scratch, and no compiler-emitted instruction outside ;;#ASMSTART .. ;;#ASMEND names
-//    v32..v127 or s80..s95 - a spill lane parked in the hand-owned file would corrupt results silently) and every
-//    hand-written statement names the whole hand-owned file in its clobber list;
+//    weight / address registers.  They carry state ACROSS statements and are touched exclusively by literal-register
+//    inline asm, so the compiler never copies or spills them.  The contract is ENFORCED at build time
+//    (build.audit_flat4: 0 spilled SGPRs / VGPRs, no scratch, and no compiler-emitted instruction outside ;;#ASMSTART ..
+//    ;;#ASMEND names v32..v127 - a spill lane parked in the hand-owned file would corrupt results silently) and every
+//    hand-written statement names the whole hand-owned file in its clobber list.  The literal SCALAR registers s[80:95]
+//    (per-entry scalars, DMA addresses) are statement-local - written and read inside ONE asm statement that lists them
+//    as clobbers - so the compiler may use them between statements and no SGPR budget is imposed (rounds 1-3 capped it
+//    at s[0:79], which cost 3 .. 20 spilled SGPRs);
 //  * the destination row of an entry is a run-time value: the accumulators are addressed through GPR-index mode
 //    (s_set_gpr_idx_on: VGPR number += M0[7:0]), so there is no per-row control flow;
 //  * the per-entry loop is the generated straight-line pipeline of gen_flat_asm.py (4 VALU per entry);
@@ -207,7 +210,7 @@ template <int SET> __device__ __forceinline__ int2 chunk_get() {
 }
 
 template <typename TOut, int EPI, bool DBG>
-__global__ void __launch_bounds__(kTW * 64) __attribute__((amdgpu_num_vgpr(16), amdgpu_num_sgpr(80)))
+__global__ void __launch_bounds__(kTW * 64) __attribute__((amdgpu_num_vgpr(16)))
 agg_tiled_flat4(const KArgs a, const TArgs t) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int row_bytes = 1024;                      // LDS row stride: fixed, so that {LDS row address | 4*slot} packs into one dword
@@ -425,6 +428,7 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
             const bool lane_on = lane * 4 < a.D;
             const bool no_mean = a.flags & WGNN_FLAG_NO_MEAN, relu = a.flags & WGNN_FLAG_RELU;
             const bool has_self = !(a.flags & WGNN_FLAG_NO_SELF) && a.self != nullptr;
+            const bool out_scale = (a.flags & WGNN_FLAG_OUT_SCALE_ALPHA) && a.mode == WGNN_DST_IS_GENE;
             // per-row factors (inv_deg, alpha: inputs nobody writes during the launch) come through the scalar cache like
             // the item words: the rows are wave-uniform, and as SGPR values they cost no vector registers - the compiler
             // owns v[0:31] only and this epilogue is the place where it needs them all
@@ -436,7 +440,7 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
             for (int i0 = 0; i0 < kRPW; i0 += 2) {
                 int slot[2], pslot[2];
                 float4 sf[2];
-                float invd[2], rs[2];
+                float invd[2], rs[2], post[2];
                 // the lane's byte offset inside a row, opaque per trip: every access below is then "uniform row base
                 // (SGPR pair) + 32-bit lane offset" - left visible, the offset is folded into each of the four base
                 // pointers ahead of the loop, i.e. four 64-bit per-lane addresses (8 VGPRs) held across it
@@ -464,10 +468,12 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
                 }
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
-                    invd[k] = 1.0f; rs[k] = 1.0f;
+                    invd[k] = 1.0f; rs[k] = 1.0f; post[k] = 1.0f;
                     if (slot[k] >= 0 && pslot[k] < 0) {
                         if (!no_mean) invd[k] = a.inv_deg ? s_inv_deg[slot[k]] : 1.0f / (row_degree(a, slot[k]) + 1.0f);
-                        rs[k] = invd[k] * (a.mode == WGNN_DST_IS_GENE ? s_alpha[slot[k]] : 1.0f);
+                        const float a_row = a.mode == WGNN_DST_IS_GENE ? s_alpha[slot[k]] : 1.0f;   // one load serves both uses
+                        rs[k] = invd[k] * a_row;
+                        post[k] = a_row;
                     }
                 }
 #pragma unroll
@@ -483,6 +489,7 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
                     if (has_self) fma4(o, invd[k] * a_self, sf[k]);
                     if (a.bias) { o.x += bias4.x; o.y += bias4.y; o.z += bias4.z; o.w += bias4.w; }
                     if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                    if (out_scale) { o.x *= post[k]; o.y *= post[k]; o.z *= post[k]; o.w *= post[k]; }
                     if (lane_on) *at(outp, slot[k], a.ld_out) = f4v{o.x, o.y, o.z, o.w};
                 }
             }

@@ -54,6 +54,22 @@ def comm_active() -> bool:
     return dist.get_world_size() > 1 or FORCE_COLLECTIVES
 
 
+# hipGraph capture of the sharded forward (graphed.GraphedShardedForward).  With RCCL the data-path collectives are captured
+# with the kernels (one graph launch per forward).  A backend whose collectives run on the host (gloo: the shared-GPU debug
+# mode and the CPU tests) cannot be captured; there the capture is cut at every collective: ``COLLECTIVE_HOOK(fn)`` - set by
+# the capturing object for the duration of the capture - ends the current graph segment, runs ``fn`` eagerly, remembers it
+# for replay and opens the next segment.
+COLLECTIVE_HOOK: Optional[Callable] = None
+
+
+def _issue(fn: Callable):
+    """Run one data-path collective ``fn()`` (returns a Work handle or None) - through the capture hook when one is set."""
+    if COLLECTIVE_HOOK is not None:
+        COLLECTIVE_HOOK(fn)
+        return None
+    return fn()
+
+
 def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
     if comm_active():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
@@ -112,9 +128,12 @@ class LocalOps:
                                #  self_compact: p_c_local already holds one row per entry of rows)
     genes_partial: Callable    # (p_c_local)                               -> partial [G, H] (plain weighted sum)
     genes_finish: Callable     # (partial_sum_global, p_g, bias, relu)     -> h_g'
-    cells_mean_linear: Optional[Callable] = None   # (h_g, h_c_local, W, bias, relu[, rows, self_compact]) -> the LAST layer in the
-                               #  reference's literal order, act(mean-aggregation W^T + b): at equal widths it skips the
-                               #  replicated [G, H] x [H, H] product of project-first (used when nothing is differentiated)
+    cells_mean_linear: Optional[Callable] = None   # (h_g, h_c_local, W, bias, relu[, rows, self_compact, prescaled]) -> the LAST
+                               #  layer in the reference's literal order, act(mean-aggregation W^T + b): at equal widths it skips
+                               #  the replicated [G, H] x [H, H] product of project-first (used when nothing is differentiated)
+    fold_alpha_ok: Optional[Callable] = None       # (width, n_seed_rows | None) -> bool: genes_finish(..., scale_out=True) may write the
+                               #  gene rows alpha-folded and cells_mean_linear(..., prescaled=True) reads them as its source
+                               #  table without a scale launch (HIP binding only)
 
 
 def dropout_mask(shape, p: float, generator: Optional[torch.Generator], device, dtype=torch.float32) -> torch.Tensor:
@@ -140,6 +159,7 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
     layer i (gnn.py:60-64) - the gene mask must be identical on every rank (see :func:`dropout_mask`)."""
     h_g, h_c = feats_g, feats_c_local
     compact = False                                     # h_c holds the seeds' rows only (see GNN.embed for the rule)
+    folded = False                                      # h_g holds alpha-folded gene rows (written so by genes_finish)
     for i in range(n_layers):
         W, b = weights[i]
         last = i == n_layers - 1
@@ -151,8 +171,9 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
             h_g, h_c = h_g.to(m_g.dtype) * m_g, h_c.to(m_c.dtype) * m_c
         if (last and ops.cells_mean_linear is not None and W.shape[0] == W.shape[1] and h_g.dtype == W.dtype
                 and not torch.is_grad_enabled()):
-            h_c = (ops.cells_mean_linear(h_g, h_c, W, b, relu) if rows is None
-                   else ops.cells_mean_linear(h_g, h_c, W, b, relu, rows, compact))
+            kw = {"prescaled": True} if folded else {}
+            h_c = (ops.cells_mean_linear(h_g, h_c, W, b, relu, **kw) if rows is None
+                   else ops.cells_mean_linear(h_g, h_c, W, b, relu, rows, compact, **kw))
             break
         if getattr(linear, "widens_fp16", False):       # ops.linear: fp16-stored rows are widened inside the GEMM's loader
             p_g, p_c = linear(h_g, W), linear(h_c, W)
@@ -168,11 +189,17 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
         else:
             # the ONE data-path collective (X2) runs on the communicator's stream while this rank's
             # cells<-genes pass (row-independent, no communication) computes
-            work = dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=True) if comm_active() else None
+            overlap = COLLECTIVE_HOOK is None           # (a segmented capture runs the collective synchronously, now and at replay)
+            work = _issue(lambda: dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=overlap)) if comm_active() else None
             new_c = ops.cells_layer(p_g, p_c, b, relu) if rows is None else ops.cells_layer(p_g, p_c, b, relu, rows, False)
             if work is not None:
                 work.wait()                             # stream-level dependency on GPU backends, no host sync
-        h_g = ops.genes_finish(part, p_g, b, relu)
+        # the gene rows below a cells-only, aggregate-first last layer are only read as that layer's alpha-folded source table
+        Wn = weights[i + 1][0]
+        folded = bool(i == n_layers - 2 and ops.fold_alpha_ok is not None and ops.cells_mean_linear is not None
+                      and not torch.is_grad_enabled() and dropout_masks is None and Wn.shape[0] == Wn.shape[1] == W.shape[0]
+                      and ops.fold_alpha_ok(W.shape[0], None if seeds_local is None else int(seeds_local.shape[0])))
+        h_g = ops.genes_finish(part, p_g, b, relu, scale_out=True) if folded else ops.genes_finish(part, p_g, b, relu)
         h_c = new_c
         compact = rows is not None
     Wo, bo = weights[n_layers]
@@ -185,13 +212,14 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
             raise ValueError("gather_logits on a sharded job needs shard_sizes (cells per rank, one entry per rank)")
         if len(set(shard_sizes)) == 1:
             out = torch.empty((ws * logits.shape[0], logits.shape[1]), dtype=logits.dtype, device=logits.device)
-            work = dist.all_gather_into_tensor(out, logits.contiguous(), async_op=async_gather)    # X3: inference concat
+            mine, in_flight = logits.contiguous(), async_gather and COLLECTIVE_HOOK is None
+            work = _issue(lambda: dist.all_gather_into_tensor(out, mine, async_op=in_flight))      # X3: inference concat
             return (out, work) if async_gather else out
         mx = max(shard_sizes)                           # ragged shards: pad to the largest, gather, cut
         pad = torch.zeros(mx, logits.shape[1], dtype=logits.dtype, device=logits.device)
         pad[: logits.shape[0]] = logits
         outs = [torch.empty_like(pad) for _ in range(ws)]
-        dist.all_gather(outs, pad)
+        _issue(lambda: dist.all_gather(outs, pad))
         cat = torch.cat([o[:n] for o, n in zip(outs, shard_sizes)])
         return (cat, None) if async_gather else cat
     return (logits, None) if async_gather else logits

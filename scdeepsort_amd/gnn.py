@@ -77,25 +77,36 @@ class GNN(nn.Module):
         self.linear = nn.Linear(n_hidden, n_classes)
         nn.init.xavier_uniform_(self.linear.weight, gain=nn.init.calculate_gain('relu'))
         self.order = "auto"          # "auto" | "project_first" | "aggregate_first"
+        self.fold_alpha = True       # no-grad forward: the layer below the last writes its gene rows alpha-folded (A/B switch)
 
     # -- one NodeFlow block, both node types ------------------------------------------------------
     def _pad_width(self, g: CellGeneGraph, H: int) -> int:
         return pad_width(g.cg.nnz, H)
 
+    def _project_first(self, layer: NodeUpdate, want_genes: bool) -> bool:
+        # "auto": aggregate at the narrower width.  At EQUAL widths both orders aggregate the same bytes, but project-first
+        # multiplies every source row too (genes AND cells), aggregate-first only the rows this layer outputs: the last layer
+        # (cells only) then skips the [G, H] x [H, H] product - and is the reference's literal order (gnn.py:65-66).
+        W = layer.fc_neigh.weight
+        return self.order == "project_first" or (self.order == "auto" and (
+            W.shape[0] < W.shape[1] or (W.shape[0] == W.shape[1] and want_genes)))
+
     def _layer(self, g: CellGeneGraph, layer: NodeUpdate, h_g: torch.Tensor, h_c: torch.Tensor,
-               want_genes: bool, cell_rows: Optional[torch.Tensor], h_c_compact: bool = False):
+               want_genes: bool, cell_rows: Optional[torch.Tensor], h_c_compact: bool = False,
+               genes_out_scaled: bool = False, h_g_prescaled: bool = False):
         """One NodeFlow block for both node types.  ``cell_rows``: compute only these cell rows (a seed batch);
         ``h_c_compact``: ``h_c`` already holds one row per entry of ``cell_rows`` (the previous layer was restricted to
-        the seeds) - then cells cannot be sources at this layer (``want_genes`` is False)."""
+        the seeds) - then cells cannot be sources at this layer (``want_genes`` is False).
+        ``genes_out_scaled`` (no-grad path, decided by ``embed``): the gene rows this layer outputs are written as
+        ``alpha[g] * h_g'[g]`` by the aggregation epilogue; ``h_g_prescaled``: ``h_g`` IS such a table (this layer reads gene
+        rows only as the source of its cells<-genes pass, which then skips its scale launch)."""
         G = self.gene_num
         if h_c_compact and (want_genes or cell_rows is None):
             raise ValueError("compact cell rows can only feed the seeds' own self-loop")
         W, b = layer.fc_neigh.weight, layer.fc_neigh.bias
-        # "auto": aggregate at the narrower width.  At EQUAL widths both orders aggregate the same bytes, but project-first
-        # multiplies every source row too (genes AND cells), aggregate-first only the rows this layer outputs: the last layer
-        # (cells only) then skips the [G, H] x [H, H] product - and is the reference's literal order (gnn.py:65-66).
-        project_first = self.order == "project_first" or (self.order == "auto" and (
-            W.shape[0] < W.shape[1] or (W.shape[0] == W.shape[1] and want_genes)))
+        project_first = self._project_first(layer, want_genes)
+        if (genes_out_scaled and not (project_first and want_genes)) or (h_g_prescaled and (project_first or want_genes)):
+            raise ValueError("alpha-folded gene tables pass from a project-first layer to a cells-only aggregate-first layer")
         if h_g.shape[1] % 4:                               # e.g. dense_dim = 50: zero feature columns up to a multiple of 4
             extra = -h_g.shape[1] % 4
             h_g, h_c = F.pad(h_g, (0, extra)), F.pad(h_c, (0, extra))
@@ -148,18 +159,31 @@ class GNN(nn.Module):
                                             relu=fuse_relu, row_ids=cell_rows, self_compact=self_compact, src_scaled=p_g_scaled)
             out_g = None
             if want_genes:
-                out_g = weighted_mean_aggregate(g.gc, self.alpha, DST_IS_GENE, G, p_c_all, p_g, bias=b, relu=fuse_relu)
+                out_g = weighted_mean_aggregate(g.gc, self.alpha, DST_IS_GENE, G, p_c_all, p_g, bias=b, relu=fuse_relu,
+                                                out_scale_alpha=genes_out_scaled)
             return (finish(out_g) if out_g is not None else None), finish(out_c)
         # aggregate first (the reference's literal order: neigh -> fc_neigh -> activation)
         hc_self = h_c if (not compact or h_c_compact) else h_c[cell_rows.long()]
         z_c = weighted_mean_aggregate(g.cg, self.alpha, SRC_IS_GENE, G + 1, h_g, hc_self, row_ids=cell_rows,
-                                      self_compact=compact)
+                                      self_compact=compact, src_scaled=h_g if h_g_prescaled else None)
         out_c = _linear_act(z_c, W, b, fuse_relu)
         out_g = None
         if want_genes:
             z_g = weighted_mean_aggregate(g.gc, self.alpha, DST_IS_GENE, G, h_c, h_g)
             out_g = finish(_linear_act(z_g, W, b, fuse_relu))
         return out_g, finish(out_c)
+
+    def _fold_alpha_into_gene_rows(self, g: CellGeneGraph, layer: NodeUpdate, cell_rows) -> bool:
+        """Whether the second-to-last layer may write its gene rows alpha-folded (see ``embed``): that layer runs
+        project-first with a fused (or no) activation and no norm, the last layer runs aggregate-first at a width the tile
+        kernel carries unpadded, and its cells<-genes pass takes the LDS-streamed route (the one reading a pre-folded table)."""
+        nxt = self.layers[-1]
+        act_ok = layer.norm is None and (layer.activation is None or _is_relu(layer.activation))
+        H = layer.fc_neigh.weight.shape[0]
+        Hp = self._pad_width(g, H)
+        return (getattr(self, "fold_alpha", True) and act_ok and self._project_first(layer, True) and not self._project_first(nxt, False)
+                and Hp == H and nxt.fc_neigh.weight.shape[1] == H
+                and _ops.will_run_tiled(g.cg, H, None if cell_rows is None else int(cell_rows.shape[0])))
 
     def embed(self, g: CellGeneGraph, features: torch.Tensor, seeds: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Cell embeddings = ``nf.layers[-1].data['activation']`` (gnn.py:66) for ``seeds`` (node ids >= G)."""
@@ -193,10 +217,17 @@ class GNN(nn.Module):
         # rows only (the last layer computes no genes): a 2-layer forward on a seed batch runs ONE full pass (layer-1
         # genes) instead of two; the reference's NodeFlow closure contains exactly these nodes.
         compact = False
+        prescaled = False
         for i, layer in enumerate(self.layers):
             last = i == self.n_layers - 1
             rows = cell_rows if (cell_rows is not None and i >= self.n_layers - 2) else None
-            h_g, h_c = self._layer(g, layer, h_g, h_c, want_genes=not last, cell_rows=rows, h_c_compact=compact)
+            # The gene rows of the layer below a cells-only last layer are read ONCE more: as the source table of that layer's
+            # cells<-genes pass, which wants them alpha-folded (gnn.py:54, (h*alpha)*w).  With nothing to differentiate and
+            # that pass on the LDS-streamed kernel, this layer's epilogue writes them folded (no scale launch in between).
+            emit = (i == self.n_layers - 2 and not torch.is_grad_enabled() and self._fold_alpha_into_gene_rows(g, layer, cell_rows))
+            h_g, h_c = self._layer(g, layer, h_g, h_c, want_genes=not last, cell_rows=rows, h_c_compact=compact,
+                                   genes_out_scaled=emit, h_g_prescaled=prescaled)
+            prescaled = emit
             compact = rows is not None
         H = self.layers[-1].fc_neigh.weight.shape[0]
         return h_c if h_c.shape[1] == H else h_c[:, :H]

@@ -86,3 +86,94 @@ class GraphedTrainStep:
         self._g.replay()
         self.replays += 1
         return self._loss
+
+
+class GraphedShardedForward:
+    """hipGraph replay of the SHARDED no-grad forward (``ShardedWgnn.forward`` at world > 1): at 12.5k cells per rank
+    (cfg3 over 8 GPUs) the forward is ~15 short launches and two collectives, i.e. launch-bound when issued eagerly.
+
+    * ``nccl`` (RCCL): the collectives are captured WITH the kernels - the async [G, H] all-reduce on the communicator's
+      stream (forked from / joined to the capture stream by events, so its overlap with the cells<-genes pass is part of the
+      graph) and the logits all-gather - one graph launch per forward (``mode == "whole"``).
+    * any other backend (gloo: collectives run on the host; the shared-GPU debug mode of ``bench.py`` and the tests): the
+      capture is cut at every collective (``dist.COLLECTIVE_HOOK``): kernels replay as graph segments, the collectives in
+      between are re-issued eagerly on the same static tensors (``mode == "segments"``).
+
+    ``__call__`` returns the static output buffer (all cells' logits when ``gather_logits``), valid until the next call."""
+
+    def __init__(self, engine, feats_g: torch.Tensor, feats_c_local: torch.Tensor, gather_logits: bool = True,
+                 warmup: int = 2, mode: Optional[str] = None):
+        import torch.distributed as tdist
+        from . import dist as D
+        if engine.model.training:
+            raise ValueError("capture an eval-mode model (dropout draws a fresh mask per call)")
+        if engine.world == 1:
+            raise ValueError("world == 1: use GraphedForward")
+        self.engine, self.gather = engine, gather_logits
+        dev = engine.graph.device
+        self.device = dev
+        self.feats_g, self.feats_c = feats_g.clone(), feats_c_local.clone()
+        if mode is None:
+            mode = "whole" if (not D.comm_active() or tdist.get_backend() == "nccl") else "segments"
+        self.mode = mode
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():          # warm-up: plans, LDS attributes, allocator, communicator set-up
+            for _ in range(max(1, warmup)):
+                self.logits = engine.forward(self.feats_g, self.feats_c, gather_logits=gather_logits)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self._seq = []                                          # replay program: CUDAGraph objects and collective thunks
+        with torch.cuda.device(dev):
+            if mode == "whole":
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g), torch.no_grad():
+                    self.logits = engine.forward(self.feats_g, self.feats_c, gather_logits=gather_logits)
+                self._seq.append(g)
+            else:
+                self._capture_segments(side)
+        self.n_graphs = sum(isinstance(x, torch.cuda.CUDAGraph) for x in self._seq)
+        self.n_eager_collectives = len(self._seq) - self.n_graphs
+
+    def _capture_segments(self, side):
+        from . import dist as D
+        pool = torch.cuda.graph_pool_handle()                   # one memory pool: later segments read earlier segments' tensors
+        cur = {"g": None}
+
+        def begin():
+            cur["g"] = torch.cuda.CUDAGraph()
+            cur["g"].capture_begin(pool=pool)
+
+        def end():
+            cur["g"].capture_end()
+            self._seq.append(cur["g"])
+
+        def hook(fn):                                           # a data-path collective: cut the graph here
+            end()
+            torch.cuda.current_stream(self.device).synchronize()
+            fn()                                                # eager, synchronous (see dist.sharded_forward)
+            self._seq.append(fn)
+            begin()
+
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side), torch.no_grad():
+            D.COLLECTIVE_HOOK = hook
+            try:
+                begin()
+                self.logits = self.engine.forward(self.feats_g, self.feats_c, gather_logits=self.gather)
+                end()
+            finally:
+                D.COLLECTIVE_HOOK = None
+        torch.cuda.current_stream(self.device).wait_stream(side)
+
+    def __call__(self, feats_g: Optional[torch.Tensor] = None, feats_c_local: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if feats_g is not None:
+            self.feats_g.copy_(feats_g)
+        if feats_c_local is not None:
+            self.feats_c.copy_(feats_c_local)
+        for x in self._seq:
+            if isinstance(x, torch.cuda.CUDAGraph):
+                x.replay()
+            else:
+                x()                                             # host-side collective on the segment's static tensors
+        return self.logits

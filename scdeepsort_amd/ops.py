@@ -59,6 +59,17 @@ SEED_FULL_PASS_MIN_FRAC = 0.2       # a seed set of at least this share of the r
                                     # pass and gathers its rows (row-wave K1 costs ~5x per edge: 6.2 vs 1.19 ms for all of cfg3)
 
 
+def tiled_kernel_serves(csr: AggCsr, D: int) -> bool:
+    """True when a FULL pass over ``csr`` at width ``D`` is dispatched to the LDS-streamed kernel (K1t)."""
+    return TILED_MIN_WORK is not None and D <= 256 and D % 4 == 0 and csr.nnz * D >= TILED_MIN_WORK and csr.ell_cnt is None
+
+
+def will_run_tiled(csr: AggCsr, D: int, n_seed_rows: Optional[int] = None) -> bool:
+    """True when ``agg_fwd`` on f32 rows of width ``D`` (all rows, or a seed set of ``n_seed_rows`` rows) takes the
+    LDS-streamed route - the one that honours ``src_scaled``."""
+    return tiled_kernel_serves(csr, D) and (n_seed_rows is None or n_seed_rows >= SEED_FULL_PASS_MIN_FRAC * csr.n_rows)
+
+
 def _partials(plan: Plan, D: int, device) -> Optional[torch.Tensor]:
     return torch.empty(plan.n_partials * D, dtype=torch.float32, device=device) if plan.n_partials else None
 
@@ -68,21 +79,26 @@ def agg_fwd(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, self_idx: int
             relu: bool = False, row_ids: Optional[torch.Tensor] = None, self_compact: bool = False,
             no_mean: bool = False, out_dtype: Optional[torch.dtype] = None,
             out: Optional[torch.Tensor] = None, neigh_sum: Optional[torch.Tensor] = None,
-            src_scaled: Optional[torch.Tensor] = None) -> torch.Tensor:
+            src_scaled: Optional[torch.Tensor] = None, out_scale_alpha: bool = False) -> torch.Tensor:
     """K1 ``wgnn_agg_fwd``: weighted mean of in-neighbours incl. the implicit self-loop.  ``neigh_sum`` (f32 [n_out, D],
     contiguous) optionally receives the raw neighbour sum of every output row (saved by training for dalpha).
-    ``src_scaled`` (SRC_IS_GENE only): ``alpha[s] * h_src[s]`` already formed (``linear_fwd(..., row_scale=alpha)``) - the
-    LDS-streamed kernel then reads it in place of its own scale pass; the row-wave kernel ignores it."""
+    ``src_scaled`` (SRC_IS_GENE only): ``alpha[s] * h_src[s]`` already formed (``linear_fwd(..., row_scale=alpha)`` or a
+    gene pass run with ``out_scale_alpha``) - the LDS-streamed kernel then reads it in place of its own scale pass; the
+    row-wave kernel ignores it (callers check ``will_run_tiled`` before handing over an ONLY-scaled table).
+    ``out_scale_alpha`` (DST_IS_GENE): the finished gene rows are written multiplied by alpha[row]
+    (WGNN_FLAG_OUT_SCALE_ALPHA) - the next layer's alpha-folded source table, no separate scale launch."""
     dev = _require_cuda(h_src, h_self, alpha, bias, csr.col)
     h_src = _rowmajor(h_src)
     D = h_src.shape[1]
     if D % 4:
         raise WgnnError(f"feature width {D} must be a multiple of 4")
-    tiled_ok = (TILED_MIN_WORK is not None and out is None and h_src.dtype == torch.float32
-                and (out_dtype in (None, torch.float32)) and D <= 256 and csr.nnz * D >= TILED_MIN_WORK and csr.ell_cnt is None)
+    if out_scale_alpha and mode != DST_IS_GENE:
+        raise WgnnError("out_scale_alpha is defined for gene rows (DST_IS_GENE) only")
+    tiled_ok = (out is None and h_src.dtype == torch.float32 and (out_dtype in (None, torch.float32))
+                and tiled_kernel_serves(csr, D))
     if tiled_ok and row_ids is None:
         return agg_fwd_tiled(csr, csr.tile_plan(tiled_block_rows(D)), alpha, mode, self_idx, h_src, h_self, bias=bias, relu=relu,
-                             no_mean=no_mean, neigh_sum=neigh_sum, src_scaled=src_scaled)
+                             no_mean=no_mean, neigh_sum=neigh_sum, src_scaled=src_scaled, out_scale_alpha=out_scale_alpha)
     if (tiled_ok and neigh_sum is None and row_ids.shape[0] >= SEED_FULL_PASS_MIN_FRAC * csr.n_rows
             and (h_self is None or h_self.dtype == torch.float32)):
         # a LARGE seed set (predict.py:61-88: every test cell is a seed; fit's accuracy() over the training cells): one full
@@ -94,8 +110,11 @@ def agg_fwd(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, self_idx: int
             full_self.index_copy_(0, idl, _rowmajor(h_self))
             h_self = full_self
         full = agg_fwd_tiled(csr, csr.tile_plan(tiled_block_rows(D)), alpha, mode, self_idx, h_src, h_self, bias=bias, relu=relu,
-                             no_mean=no_mean, src_scaled=src_scaled)
+                             no_mean=no_mean, src_scaled=src_scaled, out_scale_alpha=out_scale_alpha)
         return full.index_select(0, idl)
+    if src_scaled is not None and src_scaled.data_ptr() == h_src.data_ptr():
+        raise WgnnError("an alpha-folded table without its unscaled original reached the row-wave kernel, which folds alpha "
+                        "per edge itself (callers check ops.will_run_tiled first)")
     if h_self is not None:
         h_self = _rowmajor(h_self)
         if h_self.dtype != h_src.dtype or h_self.shape[1] != D:
@@ -111,7 +130,8 @@ def agg_fwd(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, self_idx: int
     if n_out == 0:
         return out
     flags = (_lib.FLAG_RELU if relu else 0) | (_lib.FLAG_NO_MEAN if no_mean else 0) | \
-            (_lib.FLAG_NO_SELF if h_self is None else 0) | (_lib.FLAG_SELF_COMPACT if self_compact else 0)
+            (_lib.FLAG_NO_SELF if h_self is None else 0) | (_lib.FLAG_SELF_COMPACT if self_compact else 0) | \
+            (_lib.FLAG_OUT_SCALE_ALPHA if out_scale_alpha else 0)
     if alpha is not None:
         alpha = alpha.reshape(-1)
         if alpha.dtype != torch.float32 or not alpha.is_contiguous():
@@ -263,7 +283,7 @@ def tiled_block_rows(D: int) -> int:
 def agg_fwd_tiled(csr: AggCsr, tplan, alpha: Optional[torch.Tensor], mode: int, self_idx: int,
                   h_src: torch.Tensor, h_self: Optional[torch.Tensor], *, bias: Optional[torch.Tensor] = None,
                   relu: bool = False, no_mean: bool = False, neigh_sum: Optional[torch.Tensor] = None,
-                  src_scaled: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  src_scaled: Optional[torch.Tensor] = None, out_scale_alpha: bool = False) -> torch.Tensor:
     """K1t ``wgnn_agg_fwd_tiled``: same result as :func:`agg_fwd`, source table streamed through LDS.  ``src_scaled``: the
     alpha-folded source table (SRC_IS_GENE) when the caller already has it (WGNN_FLAG_SRC_PRESCALED)."""
     dev = _require_cuda(h_src, h_self, alpha, bias, csr.col)
@@ -275,7 +295,7 @@ def agg_fwd_tiled(csr: AggCsr, tplan, alpha: Optional[torch.Tensor], mode: int, 
         h_self = _rowmajor(h_self)
     out = torch.empty((csr.n_rows, D), dtype=torch.float32, device=dev)
     flags = (_lib.FLAG_RELU if relu else 0) | (_lib.FLAG_NO_MEAN if no_mean else 0) | \
-            (_lib.FLAG_NO_SELF if h_self is None else 0) | DEBUG_FLAGS
+            (_lib.FLAG_NO_SELF if h_self is None else 0) | (_lib.FLAG_OUT_SCALE_ALPHA if out_scale_alpha else 0) | DEBUG_FLAGS
     if alpha is not None:
         alpha = alpha.reshape(-1)
         if alpha.dtype != torch.float32 or not alpha.is_contiguous():
@@ -401,12 +421,15 @@ class WeightedMeanAggregate(torch.autograd.Function):
 def weighted_mean_aggregate(csr: AggCsr, alpha: torch.Tensor, mode: int, self_idx: int, h_src: torch.Tensor,
                             h_self: Optional[torch.Tensor], bias: Optional[torch.Tensor] = None, relu: bool = False,
                             row_ids: Optional[torch.Tensor] = None, self_compact: bool = False,
-                            src_scaled: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Differentiable K1 (+ fused bias / ReLU).  ``src_scaled``: the caller's alpha-folded source table - only meaningful when
-    nothing is recorded for backward (it is a function of alpha and h_src that autograd does not see)."""
-    if src_scaled is not None and not torch.is_grad_enabled():
+                            src_scaled: Optional[torch.Tensor] = None, out_scale_alpha: bool = False) -> torch.Tensor:
+    """Differentiable K1 (+ fused bias / ReLU).  ``src_scaled``: the caller's alpha-folded source table; ``out_scale_alpha``:
+    gene rows written alpha-folded for the next layer (see ``agg_fwd``) - both only when nothing is recorded for backward
+    (they are functions of alpha that autograd does not see)."""
+    if out_scale_alpha and torch.is_grad_enabled():
+        raise WgnnError("out_scale_alpha is an inference-path fusion: not differentiable")
+    if (src_scaled is not None or out_scale_alpha) and not torch.is_grad_enabled():
         return agg_fwd(csr, alpha, mode, self_idx, h_src, h_self, bias=bias, relu=relu, row_ids=row_ids,
-                       self_compact=self_compact, src_scaled=src_scaled)
+                       self_compact=self_compact, src_scaled=src_scaled, out_scale_alpha=out_scale_alpha)
     return WeightedMeanAggregate.apply(h_src, h_self, alpha, bias, csr, mode, self_idx, relu, row_ids, self_compact)
 
 

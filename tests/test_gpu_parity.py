@@ -1657,3 +1657,112 @@ def test_linear_act_fused_epilogue_and_last_layer_order():
             np.testing.assert_allclose(outs[order], want_logits, atol=TOL)
     np.testing.assert_allclose(outs["auto"], outs["project_first"], atol=2e-5)
     np.testing.assert_allclose(outs["auto"], outs["aggregate_first"], atol=2e-5)
+
+
+@pytest.mark.parametrize("route", ["row_wave", "tiled", "tiled_split"])
+def test_gene_rows_written_alpha_folded(route, monkeypatch):
+    """WGNN_FLAG_OUT_SCALE_ALPHA (round 4): a genes<-cells pass writes alpha[g] * act(mean + bias) - the next layer's
+    (h*alpha) source table of gnn.py:54 - from the row-wave epilogue, the tile kernel's two-row epilogue and agg_finalize
+    (rows cut into column splits / virtual rows)."""
+    from scdeepsort_amd import ops, graph as GR
+    c = small_case(cells=400, genes=120, dim=64, seed=77, density=0.3)
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
+    cg = O.build_csr_graph(c["expr"], c["support_mask"])
+    G = c["G"]; rng = np.random.default_rng(5)
+    alpha = rng.uniform(0.5, 1.5, G + 2).astype(np.float32); bias = rng.standard_normal(64).astype(np.float32)
+    Hg, Hc = c["feats"][:G], c["feats"][G:]
+    _, zg = O.csr_aggregate(cg, alpha, Hg.astype(np.float64), Hc.astype(np.float64))
+    want = np.maximum(zg + bias, 0) * alpha[:G, None]
+    if route == "row_wave":
+        monkeypatch.setattr(ops, "TILED_MIN_WORK", None)
+        out = sda.agg_fwd(g.gc, dev(alpha), sda.DST_IS_GENE, G, dev(Hc), dev(Hg), bias=dev(bias), relu=True, out_scale_alpha=True)
+    else:
+        tp = GR.build_tile_plan(g.gc, None if route == "tiled" else 2, 1 if route == "tiled" else 3, block_rows=16)
+        assert (tp.n_partials > 0) == (route == "tiled_split")
+        out = ops.agg_fwd_tiled(g.gc, tp, dev(alpha), sda.DST_IS_GENE, G, dev(Hc), dev(Hg), bias=dev(bias), relu=True,
+                                out_scale_alpha=True)
+    np.testing.assert_allclose(out.cpu().numpy(), want, atol=TOL)
+    with pytest.raises(sda.WgnnError):                       # defined for gene rows only
+        sda.agg_fwd(g.cg, dev(alpha), sda.SRC_IS_GENE, G + 1, dev(Hg), dev(Hc), out_scale_alpha=True)
+
+
+@pytest.mark.parametrize("seeded", [False, True])
+def test_nograd_forward_folds_alpha_into_the_gene_rows_below_the_last_layer(seeded, monkeypatch):
+    """2-layer no-grad forward on the LDS-streamed route: layer 1's gene pass writes its rows alpha-folded and layer 2's
+    cells<-genes pass reads them as WGNN_FLAG_SRC_PRESCALED (no scale launch) - equal to the unfused forward and the
+    oracle; with grad enabled, with a small seed batch (row-wave route) or a project-first last layer nothing is folded."""
+    from scdeepsort_amd import ops
+    c = small_case(cells=220, genes=90, dim=40, hidden=24, n_classes=5, seed=43, test_cells=15)
+    sd = O.init_params(40, 24, 5, 2, 90, seed=3)
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
+    m = make_model(sd, 40, 24, 5, 2, 90)
+    monkeypatch.setattr(ops, "TILED_MIN_WORK", 1)
+    seeds = torch.arange(90 + 20, 90 + 220, device=DEV) if seeded else None
+    calls = []
+    real = ops.agg_fwd_tiled
+    def spy(csr, tplan, alpha, mode, self_idx, h_src, h_self, **kw):
+        calls.append((mode, bool(kw.get("out_scale_alpha")), kw.get("src_scaled") is not None))
+        return real(csr, tplan, alpha, mode, self_idx, h_src, h_self, **kw)
+    monkeypatch.setattr(ops, "agg_fwd_tiled", spy)
+    with torch.no_grad():
+        folded = m(g, dev(c["feats"]), seeds=seeds)
+    assert (sda.DST_IS_GENE, True, False) in calls and (sda.SRC_IS_GENE, False, True) in calls, calls
+    calls.clear()
+    m.fold_alpha = False
+    with torch.no_grad():
+        plain = m(g, dev(c["feats"]), seeds=seeds)
+    assert not any(c_[1] or c_[2] for c_ in calls), calls
+    rg = O.build_reference_graph(c["expr"], c["support_mask"])
+    ids = np.arange(90 + 20, 90 + 220) if seeded else np.arange(90, 90 + 220)
+    want = O.nodeflow_forward(sd, rg, torch.from_numpy(c["feats"]), ids, 2).numpy()
+    np.testing.assert_allclose(folded.cpu().numpy(), want, atol=TOL)
+    np.testing.assert_allclose(plain.cpu().numpy(), want, atol=TOL)
+    assert (folded - plain).abs().max().item() < 2e-6
+    # not folded: training (autograd must see alpha), a small seed batch (row-wave kernel folds alpha per edge itself),
+    # a project-first last layer (it projects the UNSCALED gene rows)
+    m.fold_alpha = True
+    for kw, setup in (({"seeds": seeds}, "grad"), ({"seeds": torch.arange(90, 95, device=DEV)}, "small"), ({"seeds": seeds}, "pf")):
+        calls.clear()
+        m.order = "project_first" if setup == "pf" else "auto"
+        if setup == "grad":
+            out = m(g, dev(c["feats"]), **kw)
+        else:
+            with torch.no_grad():
+                out = m(g, dev(c["feats"]), **kw)
+        assert not any(c_[1] for c_ in calls), (setup, calls)
+        assert torch.isfinite(out).all()
+    m.order = "auto"
+
+
+def test_sharded_branch_folds_alpha_in_genes_finish(monkeypatch):
+    """The sharded branch (one shard holding every cell, no process group: the collectives are skipped, everything else is
+    the N > 1 path) on the LDS-streamed route: `genes_finish` writes the all-reduced gene rows alpha-folded and the last
+    layer's cells<-genes pass reads them pre-scaled - equal to the plain forward; off on the row-wave route."""
+    from scdeepsort_amd import ops, synthetic as S
+    from scdeepsort_amd.sharded import ShardedWgnn
+    G, C, Din, H = 200, 700, 40, 32
+    rp, col, val = S.synth_expression(C, G, 0.1, device=DEV)
+    torch.manual_seed(2)
+    m = sda.GNN(Din, H, 5, 2, G, activation=F.relu).to(DEV).eval()
+    with torch.no_grad():
+        m.alpha.uniform_(0.5, 1.5)
+    feats = S.synth_features(G + C, Din, device=DEV)
+    with torch.no_grad():
+        want = m(sda.CellGeneGraph.from_device_csr(rp, col, val, G), feats)
+    eng = ShardedWgnn.build(m, rp, col, val, G, global_stats=ShardedWgnn.gene_stats(col, val, G))
+    assert eng.world == 2
+    seen = []
+    real = ops.agg_fwd
+    def spy(csr, alpha, mode, self_idx, h_src, h_self, **kw):
+        seen.append((mode, bool(kw.get("out_scale_alpha")), kw.get("src_scaled") is not None))
+        return real(csr, alpha, mode, self_idx, h_src, h_self, **kw)
+    import scdeepsort_amd.sharded as SH
+    monkeypatch.setattr(SH, "agg_fwd", spy); monkeypatch.setattr(ops, "agg_fwd", spy)
+    for tiled in (True, False):
+        monkeypatch.setattr(ops, "TILED_MIN_WORK", 1 if tiled else None)
+        seen.clear()
+        with torch.no_grad():
+            got = eng.forward(feats[:G], feats[G:], gather_logits=False)
+        np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), atol=2e-5)
+        assert ((sda.DST_IS_GENE, True, False) in seen) == tiled, seen          # genes_finish(scale_out=True)
+        assert ((sda.SRC_IS_GENE, False, True) in seen) == tiled, seen          # last layer reads the folded rows
