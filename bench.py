@@ -257,7 +257,7 @@ def main():
     # (graphed.GraphedShardedForward; with a host-side backend such as gloo: graph segments around eager collectives)
     graphed = (world == 1 and (args.graphed == "on" or (args.graphed == "auto" and cfg.cells * cfg.genes <= 100_000_000))) \
         or (world > 1 and args.graphed != "off")
-    step_fn, launch_desc = None, "eager"
+    step_fn, launch_desc, launch_calibration = None, "eager", None
     if graphed and world == 1:
         from scdeepsort_amd.graphed import GraphedForward
         gf = GraphedForward(model, engine.graph, torch.cat([feats_g, feats_c]))
@@ -268,6 +268,20 @@ def main():
         step_fn = lambda: gf()
         launch_desc = ("hipGraph replay (1 launch per step, RCCL collectives captured)" if gf.mode == "whole" else
                        f"hipGraph replay in {gf.n_graphs} segments around {gf.n_eager_collectives} host-side collectives ({backend})")
+        if args.graphed == "auto":
+            # Measured on the 1-GPU lease (profiles/r04_shard_trace.json): one rank's shard at N = 4 / 8 is GPU-bound, not
+            # launch-bound - its ~15 kernels add up to the forward's wall time, the host runs ahead - and a graph replay costs
+            # its fixed launch overhead on top (0.596 eager vs 0.637 ms replayed at 12.5k cells).  So "auto" times a few steps
+            # of both, every rank takes the job-wide faster one (max over ranks, same decision everywhere), both are reported.
+            cal = {}
+            for name, fn in (("graphed", step_fn), ("eager", None)):
+                cal[name] = timed_steps(engine, feats_g, feats_c, max(3, min(10, args.steps)), 2, world, dev, profile=False, step=fn)[0]
+            launch_calibration = {k: round(v / max(3, min(10, args.steps)) * 1e3, 4) for k, v in cal.items()}
+            if cal["eager"] <= cal["graphed"]:
+                step_fn, graphed = None, False
+                launch_desc = f"eager (measured faster than the captured graph: {launch_calibration} ms per step)"
+            else:
+                launch_desc += f" (measured faster than eager: {launch_calibration} ms per step)"
     dt, dt_local, prof, out = timed_steps(engine, feats_g, feats_c, args.steps, args.warmup, world, dev, step=step_fn)
     assert torch.isfinite(out).all()
     eager_ms = None
@@ -406,7 +420,7 @@ def main():
                            "cells_total": total_cells, "cells_this_rank": C,
                            "nnz_per_gpu": per_gpu[0]["nnz"] if per_gpu else roofline["passes"][0]["nnz"],
                            "parallelism": f"cell-shard x{world}", "setup_s": round(t_setup, 1), "communicator": comm,
-                           "step_launch": launch_desc, "eager_ms_per_step": eager_ms,
+                           "step_launch": launch_desc, "eager_ms_per_step": eager_ms, "launch_calibration_ms": launch_calibration,
                            "sharded_vs_unsharded": self_check},
                 "roofline": roofline, "cpu_baseline": cpu, "sustained": sustained, "weak_scaling": weak}
         print(json.dumps(line))

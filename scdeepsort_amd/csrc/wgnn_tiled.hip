@@ -40,6 +40,9 @@ constexpr unsigned kDbgNoFill = 1u << 16, kDbgNoCompute = 1u << 17, kDbgNoBarrie
 constexpr unsigned kDbgSkipHubShift = 21;          // bits 21..23 = n: skip the entry pipeline of the first 2n LDS blocks (prices a dense treatment of hub sources)
 constexpr unsigned kDbgFillToVgpr = 1u << 20;      // the fill's loads go to scratch VGPRs instead of LDS: same VMEM issue / L2 traffic, no LDS writes
 
+// LDS row stride of agg_tiled_flat4 (host and device): D*4 bytes rounded up to a multiple of 256, at most 1 KiB
+__host__ __device__ inline int flat_lds_row_bytes(int D) { const int b = (D * 4 + 255) & ~255; return b < 1024 ? b : 1024; }
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 typedef const __attribute__((address_space(4))) int* cptr_t;      // immutable plan data -> scalar (SMEM) loads
@@ -213,7 +216,11 @@ template <typename TOut, int EPI, bool DBG>
 __global__ void __launch_bounds__(kTW * 64) __attribute__((amdgpu_num_vgpr(16)))
 agg_tiled_flat4(const KArgs a, const TArgs t) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int row_bytes = 1024;                      // LDS row stride: fixed, so that {LDS row address | 4*slot} packs into one dword
+    // LDS row stride: the row's bytes rounded up to a multiple of 256 (512 B at D = 128, 1 KiB for D > 192), so that an LDS
+    // row address has zero low byte and {row address (bits 8..17) | 4*slot (bits 2..5)} packs into one dword.  Rounds 2-3
+    // kept 1 KiB whatever D was: at D = 128 half of every LDS block was dead (78 rows per block where 156 fit - twice the
+    // barriers and pipeline warm-ups per edge).
+    const int row_bytes = flat_lds_row_bytes(a.D);
     const int g_row = a.D * (int)sizeof(float);          // global row stride: D <= 256 floats (lanes >= D/4 carry nothing)
     const int n4 = a.D >> 2;                             // lanes that move 16 B of a row in the global->LDS DMA
     const int kKB = t.kb, buf_bytes = kKB * row_bytes;
@@ -232,7 +239,7 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
         asm volatile("s_set_gpr_idx_on %0, gpr_idx(DST)\n\tv_mov_b32 v64, 0\n\tv_mov_b32 v65, 0\n\t"
                      "v_mov_b32 v66, 0\n\tv_mov_b32 v67, 0\n\ts_set_gpr_idx_off" ::"s"(r * 4) : WGNN_CLOB);
 
-    const int lane16 = lane * 16, row_mask = 0x3FC00;     // LDS row address bits of a packed entry
+    const int lane16 = lane * 16, row_mask = 0x3FF00;     // LDS row address bits of a packed entry (rows start at multiples of 256)
     // global -> LDS DMA of `rows` source rows starting at global row r0 into LDS buffer `buf`: one 1 KiB row per
     // wave-instruction; the first `nw` waves take part, wave w takes rows w, w + nw, ... (nw = 16: every wave, <= 5 pieces
     // per block; nw = 2 dedicated loader waves: 39 each).  Scalar base + lane offset addressing: no VALU, 6 SALU per row.
@@ -303,9 +310,9 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
     const int wstrip_addr = (int)(size_t)smem + 2 * buf_bytes + wave * 256;
     const int wlane_addr = wstrip_addr + lane * 4;
     auto consume = [&](const int2& ent, int n, int buf_addr) {
-        // packed entry: LDS address of the source row (bits 10..17) | 4*slot (bits 0..7) | 4*slot of the pair's second
+        // packed entry: LDS address of the source row (bits 8..17) | 4*slot (bits 0..7) | 4*slot of the pair's second
         // entry (bits 18..25; only the first entry of a shared pair carries one)
-        const int pk = (buf_addr + ((ent.x & 0xFF) << 10)) | (((ent.x >> 8) & 0xF) << 2) | (((ent.x >> 16) & 0xF) << 20);
+        const int pk = (buf_addr + (ent.x & 0xFF) * row_bytes) | (((ent.x >> 8) & 0xF) << 2) | (((ent.x >> 16) & 0xF) << 20);
         const bool mine = lane >= 64 - n;
         const int wv = mine ? ent.y : 0;                                   // padding lanes: weight 0
         const int m = (n + 1) >> 1;
@@ -511,10 +518,10 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
     }                                                    // ---- epilogue scope
 }
 
-// LDS bytes of one launch: the flat kernel keeps 1 KiB LDS rows whatever D is (+ the per-wave weight strips)
+// LDS bytes of one launch: the flat kernel's LDS rows are D*4 bytes rounded up to 256 (+ the per-wave weight strips)
 inline bool use_flat(int D, unsigned flags) { return D <= 256 && !(flags & (1u << 19)); }   // bit 19: force the generic kernel (A/B)
 inline long tiled_lds_bytes(int D, int block_rows, unsigned flags) {
-    return use_flat(D, flags) ? 2L * block_rows * 1024 + kWStripBytes : 2L * block_rows * D * (long)sizeof(float);
+    return use_flat(D, flags) ? 2L * block_rows * flat_lds_row_bytes(D) + kWStripBytes : 2L * block_rows * D * (long)sizeof(float);
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE property of a kernel: the "already raised to" mark is kept

@@ -273,11 +273,23 @@ def agg_bwd_alpha(csr: AggCsr, g: torch.Tensor, h_src: torch.Tensor, h_self: Opt
     return d_row, d_self
 
 
+NARROW_LDS_ROWS = True       # round 4: LDS rows of the flat tile kernel are D*4 bytes rounded up to 256 (False: 78-row blocks for
+                             # every D, the round-2/3 geometry - the kernel itself always packs; kept for A/B timing)
+
+
+def flat_lds_row_bytes(D: int) -> int:
+    """LDS row stride of ``agg_tiled_flat4`` (csrc/wgnn_tiled.hip::flat_lds_row_bytes)."""
+    return min(1024, -(-D * 4 // 256) * 256)
+
+
 def tiled_block_rows(D: int) -> int:
-    """Source rows per LDS block of the tile kernels: 78 x 1 KiB x 2 buffers + the 4 KiB of per-wave weight strips = all
-    160 KiB of a CU (measured best).  The flat kernel keeps 1 KiB LDS rows for every D <= 256 (a narrower row fills the
-    head of its slot; only D/4 lanes take part in the global->LDS DMA)."""
-    return 78
+    """Source rows per LDS block of the tile kernels: two buffers + the 4 KiB of per-wave weight strips fill the 160 KiB of
+    a CU (measured best at D = 256: 78 x 1 KiB x 2).  Narrower rows pack closer (row stride = D*4 bytes rounded up to 256):
+    156 rows per block at D <= 128, 104 at D <= 192 - half / two thirds of the per-block barriers and pipeline warm-ups
+    per edge.  An entry names its source row inside a block with 8 bits, so a block holds at most 255 rows (D <= 64)."""
+    if not NARROW_LDS_ROWS:
+        return 78
+    return min(255, (160 * 1024 - 4096) // 2 // flat_lds_row_bytes(D))
 
 
 def agg_fwd_tiled(csr: AggCsr, tplan, alpha: Optional[torch.Tensor], mode: int, self_idx: int,

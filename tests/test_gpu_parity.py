@@ -1678,7 +1678,7 @@ def test_gene_rows_written_alpha_folded(route, monkeypatch):
         out = sda.agg_fwd(g.gc, dev(alpha), sda.DST_IS_GENE, G, dev(Hc), dev(Hg), bias=dev(bias), relu=True, out_scale_alpha=True)
     else:
         tp = GR.build_tile_plan(g.gc, None if route == "tiled" else 2, 1 if route == "tiled" else 3, block_rows=16)
-        assert (tp.n_partials > 0) == (route == "tiled_split")
+        assert tp.n_col_splits == (3 if route == "tiled_split" else 1) and (tp.n_partials > 0 or route == "tiled")
         out = ops.agg_fwd_tiled(g.gc, tp, dev(alpha), sda.DST_IS_GENE, G, dev(Hc), dev(Hg), bias=dev(bias), relu=True,
                                 out_scale_alpha=True)
     np.testing.assert_allclose(out.cpu().numpy(), want, atol=TOL)
@@ -1766,3 +1766,57 @@ def test_sharded_branch_folds_alpha_in_genes_finish(monkeypatch):
         np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), atol=2e-5)
         assert ((sda.DST_IS_GENE, True, False) in seen) == tiled, seen          # genes_finish(scale_out=True)
         assert ((sda.SRC_IS_GENE, False, True) in seen) == tiled, seen          # last layer reads the folded rows
+
+
+@pytest.mark.parametrize("D", [32, 64, 100, 128, 132, 192, 200, 256])
+@pytest.mark.parametrize("direction", ["cells", "genes"])
+def test_tile_kernel_packed_lds_rows_at_full_block_height(D, direction):
+    """Round 4: the flat tile kernel's LDS rows are D*4 bytes rounded up to 256 (512 B at D = 128 instead of a 1 KiB slot),
+    and `ops.tiled_block_rows(D)` fills the 160 KiB of a CU with them: 255 / 156 / 104 / 78 source rows per block.  Every
+    stride at its full block height (several blocks per tile, column splits, loader wave, shared pairs), forward and the
+    two backward entries, against the oracle / the row-wave kernels."""
+    from scdeepsort_amd.graph import build_tile_plan
+    from scdeepsort_amd import ops
+    kb = ops.tiled_block_rows(D)
+    assert kb == {256: 255, 512: 156, 768: 104, 1024: 78}[ops.flat_lds_row_bytes(D)]
+    assert 2 * kb * ops.flat_lds_row_bytes(D) + 4096 <= 160 * 1024
+    c = small_case(cells=900, genes=640, dim=D, seed=D + 3, density=0.2, test_cells=40)
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
+    cg = O.build_csr_graph(c["expr"], c["support_mask"])
+    G = c["G"]; rng = np.random.default_rng(9)
+    alpha = rng.uniform(0.5, 1.5, G + 2).astype(np.float32); bias = rng.standard_normal(D).astype(np.float32)
+    Hg, Hc = c["feats"][:G], c["feats"][G:]
+    zc, zg = O.csr_aggregate(cg, alpha, Hg.astype(np.float64), Hc.astype(np.float64))
+    ops.PROFILE = []
+    for geom in ((None, 1), (3, 2)):
+        if direction == "cells":
+            tp = build_tile_plan(g.cg, *geom, block_rows=kb, n_loaders=1)
+            out = ops.agg_fwd_tiled(g.cg, tp, dev(alpha), sda.SRC_IS_GENE, G + 1, dev(Hg), dev(Hc), bias=dev(bias), relu=True)
+            want = np.maximum(zc + bias, 0)
+        else:
+            tp = build_tile_plan(g.gc, *geom, block_rows=kb, n_loaders=1)
+            out = ops.agg_fwd_tiled(g.gc, tp, dev(alpha), sda.DST_IS_GENE, G, dev(Hc), dev(Hg), bias=dev(bias), relu=True)
+            want = np.maximum(zg + bias, 0)
+        assert tp.block_rows == kb and tp.nblk_max >= (2 if geom[1] == 1 else 1)
+        np.testing.assert_allclose(out.cpu().numpy(), want, atol=TOL)
+    assert {dict(zip(t[::2], t[1::2]))["kernel"] for t, _, _ in ops.PROFILE} == {"agg_tiled_flat4"}
+    ops.PROFILE = None
+    # backward entries K2t / K3t on the same block height against the row-wave K2 / K3
+    csr = g.cg if direction == "cells" else g.gc
+    mode = sda.SRC_IS_GENE if direction == "cells" else sda.DST_IS_GENE
+    gr = dev(rng.standard_normal((csr.n_rows, D)).astype(np.float32))
+    h_src = dev(Hg if direction == "cells" else Hc)
+    saved = ops.TILED_MIN_WORK
+    try:
+        res = {}
+        for thr in (None, 1):
+            ops.TILED_MIN_WORK = thr
+            dal = torch.zeros(G + 2, device=DEV)
+            dh = ops.agg_bwd_src(csr, dev(alpha), mode, gr, h_src if direction == "cells" else None, dal if direction == "cells" else None)
+            res[thr] = (dh.clone(), dal.clone())
+            if direction == "genes":
+                res[thr] += ops.agg_bwd_alpha(csr, gr, h_src, dev(Hg))
+    finally:
+        ops.TILED_MIN_WORK = saved
+    for a_, b_ in zip(res[None], res[1]):
+        np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), atol=2e-4, rtol=1e-4)
