@@ -53,7 +53,7 @@ def main():
     rp, col, val = (rp[lo:hi + 1] - rp[lo]).clone(), col[b:e].clone(), val[b:e].clone()
     torch.manual_seed(1234)                                           # identical initial parameters on every rank
     model = sda.GNN(cfg.dense_dim, cfg.hidden, cfg.n_classes, cfg.n_layers, G, activation=F.relu, dropout=0.1).to(dev)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=5e-4, fused=True)     # train.py:34-35 in one multi-tensor launch
     engine = ShardedWgnn.build(model, rp, col, val, G)
     feats_g = S.synth_features(G, cfg.dense_dim, seed=7, device=dev)
     feats_c = S.synth_features(cfg.cells, cfg.dense_dim, seed=100, device=dev)[lo:hi].clone()

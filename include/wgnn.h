@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define WGNN_VERSION 202           /* 0.2.x - INCOMPATIBLE with 0.1.x binders: `neigh_sum` was inserted before `n_out` in
+#define WGNN_VERSION 203           /* 0.2.x - INCOMPATIBLE with 0.1.x binders: `neigh_sum` was inserted before `n_out` in
                                       wgnn_agg_fwd / wgnn_agg_fwd_tiled (0.1.1, should have been a major bump then - a 0.1.0
                                       caller would pass n_out in a pointer slot); 0.2.0 adds int64 row pointers
                                       (WGNN_FLAG_ROWPTR_I64, wgnn_normalize_rows_i64), WGNN_FLAG_SRC_PRESCALED and
@@ -50,7 +50,8 @@ extern "C" {
                                       0.2.1: tile-plan entries may mark shared pairs (see wgnn_agg_fwd_tiled); a 0.2.0
                                       library would misread the marks, so a plan that carries them needs >= 201.
                                       0.2.2: WGNN_FLAG_OUT_SCALE_ALPHA (an older library ignores the bit: callers that set it
-                                      need >= 202). */
+                                      need >= 202).  0.2.3: wgnn_agg_bwd_prepare, wgnn_ce_sum_fwd_bwd; wgnn_agg_bwd_src_tiled
+                                      takes col_scale == NULL (pre-scaled gradient rows). */
 
 /* error codes */
 #define WGNN_OK                 0
@@ -238,7 +239,8 @@ int wgnn_agg_bwd_alpha(const int32_t* rowptr, const int32_t* col, const float* v
 /* ---------------------------------------------------------------------------
  * K2t / K3t  LDS-streamed variants of K2 / K3 (D <= 256, f32, contiguous rows), same tile-plan layout as K1t.
  *   K2t runs over the tile plan of the TRANSPOSED structure; `col_scale[r]` = inv_deg[r] (x alpha[r] for
- *   WGNN_DST_IS_GENE) is folded into the gradient rows once (g_scratch: float[n_dst*D]).
+ *   WGNN_DST_IS_GENE) is folded into the gradient rows once (g_scratch: float[n_dst*D]); col_scale == NULL (0.2.3): `g`
+ *   already carries that factor (written so by wgnn_agg_bwd_prepare) and is read as the source table, no scale pass.
  *   K3t runs over the forward structure's tile plan.
  * ------------------------------------------------------------------------- */
 int wgnn_agg_bwd_src_tiled(const float* alpha, int alpha_mode, const float* col_scale,
@@ -332,6 +334,35 @@ int wgnn_agg_linear_relu_fwd(const void* rowptr /* as wgnn_agg_fwd */, const int
                              float* neigh_scratch,
                              const float* W, int64_t ld_w, const float* bias, int32_t H, uint32_t lin_flags,
                              float* out, int64_t ld_out, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Fused glue of the training step (0.2.3; reference train.py:80-87 through torch autograd).
+ *
+ * wgnn_agg_bwd_prepare: everything the backward of ONE aggregation pass derives from the upstream gradient, in one read of it
+ * (full passes: one gradient row per CSR row, f32):
+ *     g             = gout * (out > 0)              out = the saved forward output (NodeUpdate's ReLU, gnn.py:21-22) or NULL
+ *     g_scaled[r]   = inv_deg[r] * (alpha[r] for WGNN_DST_IS_GENE) * g[r]      float[n_rows, D]: K2t's source table (col_scale NULL)
+ *     dh_self[r]    = alpha[self_idx] * inv_deg[r] * g[r]                       gradient of the self rows (alpha = 1 for WGNN_NO_ALPHA)
+ *     dalpha_row[r] = inv_deg[r] * < g[r], neigh_sum[r] >                       neigh_sum: the raw sums K1 saved (float[n_rows, D])
+ *     dself_row[r]  = inv_deg[r] * < g[r], h_self[r] >                          the caller sums it into dalpha[self_idx]
+ *     dbias[c]      = sum_r g[r, c]                                              block partials in `workspace`, folded in fixed order
+ *   Any of g_scaled / dh_self / dalpha_row / dself_row / dbias may be NULL.  inv_deg NULL = 1.  D <= 1024, multiples of 4.
+ *   workspace: wgnn_agg_bwd_prepare_workspace floats (needed for dbias only).
+ *
+ * wgnn_ce_sum_fwd_bwd: CrossEntropyLoss(reduction='sum') (train.py:36) over float logits[n_rows, n_classes] and int64 labels:
+ *     *loss_sum = sum_r ( logsumexp(logits[r]) - logits[r, labels[r]] ) ;  dlogits[r] = softmax(logits[r]) - onehot(labels[r])
+ *   (dlogits may be NULL).  workspace: wgnn_ce_sum_workspace floats.  Deterministic (fixed-order folds, no atomics).
+ * ------------------------------------------------------------------------- */
+int wgnn_agg_bwd_prepare_workspace(int64_t n_rows, int32_t D, int64_t* floats);
+int wgnn_agg_bwd_prepare(const float* gout, int64_t ld_gout, const float* out, int64_t ld_out,
+                         const float* inv_deg, const float* alpha, int alpha_mode, int32_t self_idx,
+                         float* g_scaled, const float* h_self, int64_t ld_self, float* dh_self, int64_t ld_dh,
+                         const float* neigh_sum, float* dalpha_row, float* dself_row, float* dbias,
+                         int64_t n_rows, int32_t D, float* workspace, int64_t workspace_floats, void* stream);
+int wgnn_ce_sum_workspace(int64_t n_rows, int64_t* floats);
+int wgnn_ce_sum_fwd_bwd(const float* logits, int64_t ld_logits, const int64_t* labels, int64_t n_rows, int32_t n_classes,
+                        float* loss_sum, float* dlogits, int64_t ld_dlogits, float* workspace, int64_t workspace_floats,
+                        void* stream);
 
 #ifdef __cplusplus
 }

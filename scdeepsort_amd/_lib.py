@@ -16,7 +16,7 @@ SRC_IS_GENE, DST_IS_GENE, NO_ALPHA = 0, 1, 2
 F32, F16 = 0, 1
 FLAG_RELU, FLAG_NO_MEAN, FLAG_NO_SELF, FLAG_SELF_COMPACT, FLAG_ROWPTR_I64, FLAG_SRC_PRESCALED, FLAG_OUT_SCALE_ALPHA = 1, 2, 4, 8, 16, 32, 64
 ABI_MAJOR = 2                      # include/wgnn.h WGNN_VERSION / 100
-ABI_MIN = 202                      # 0.2.1: shared-pair marks in tile-plan entries; 0.2.2: WGNN_FLAG_OUT_SCALE_ALPHA (gnn.GNN sets it)
+ABI_MIN = 203                      # 0.2.1: shared-pair marks in tile-plan entries; 0.2.2: WGNN_FLAG_OUT_SCALE_ALPHA (gnn.GNN sets it); 0.2.3: fused training glue
 
 _vp, _i32, _i64, _u32, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_int
 
@@ -48,6 +48,11 @@ SIGNATURES = {
     "wgnn_linear_fwd_ex": (C.c_int, [_vp, _int, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _u32, _vp]),
     "wgnn_linear_wgrad_workspace": (C.c_int, [_i64, _i32, _i32, _vp, _vp]),
     "wgnn_linear_wgrad": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _int, _vp, _i64, _vp]),
+    "wgnn_agg_bwd_prepare_workspace": (C.c_int, [_i64, _i32, _vp]),
+    "wgnn_agg_bwd_prepare": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _int, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp,
+                                       _i64, _i32, _vp, _i64, _vp]),
+    "wgnn_ce_sum_workspace": (C.c_int, [_i64, _vp]),
+    "wgnn_ce_sum_fwd_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _i64, _vp]),
     "wgnn_agg_linear_relu_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _int, _i32, _vp, _i64, _vp, _i64, _vp, _vp,
                                            _i64, _i32, _u32, _vp, _i64, _vp, _i64, _vp, _i64, _vp,
                                            _vp, _i64, _vp, _i32, _u32, _vp, _i64, _vp]),

@@ -634,18 +634,22 @@ extern "C" int wgnn_agg_bwd_src_tiled(const float* alpha, int alpha_mode, const 
                                       void* stream) {
     int rc = tiled_common_check(D, block_rows, entries, seg_ptr, tile_items, tile_hdr, n_tiles, long_rows, n_long, partials, n_partials);
     if (rc) return rc;
-    if (!g || !dh_src || !col_scale || !g_scratch || n_src < 0 || n_dst < 0) return WGNN_ERR_BAD_ARG;
+    if (!g || !dh_src || n_src < 0 || n_dst < 0) return WGNN_ERR_BAD_ARG;
+    if (col_scale && !g_scratch) return WGNN_ERR_WORKSPACE;      // col_scale == NULL: `g` already carries the per-row factors
     if (alpha_mode < WGNN_SRC_IS_GENE || alpha_mode > WGNN_NO_ALPHA) return WGNN_ERR_BAD_ARG;
     if (alpha_mode != WGNN_NO_ALPHA && !alpha) return WGNN_ERR_BAD_ARG;
     if (ld_dh % 4 || (h_src && ld_src % 4)) return WGNN_ERR_ALIGNMENT;
-    if (!aligned16(g) || !aligned16(g_scratch) || !aligned16(dh_src) || (h_src && !aligned16(h_src))) return WGNN_ERR_ALIGNMENT;
+    if (!aligned16(g) || (g_scratch && !aligned16(g_scratch)) || !aligned16(dh_src) || (h_src && !aligned16(h_src))) return WGNN_ERR_ALIGNMENT;
     if (n_src == 0 || n_tiles == 0) return WGNN_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
     // per-destination factors (inv_deg[r], x alpha[r] for cell->gene edges) are folded into the gradient rows once
-    const long n4 = (long)n_dst * (D / 4);
-    hipLaunchKernelGGL(scale_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, g, col_scale, g_scratch, (long)n_dst, D / 4);
+    // (wgnn_agg_bwd_prepare writes the gradient rows already multiplied: then col_scale is NULL and `g` is the source table)
+    if (col_scale) {
+        const long n4 = (long)n_dst * (D / 4);
+        hipLaunchKernelGGL(scale_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, g, col_scale, g_scratch, (long)n_dst, D / 4);
+    }
     KArgs a{};
-    a.src = g_scratch; a.ld_src = D; a.alpha = alpha; a.mode = alpha_mode;
+    a.src = col_scale ? g_scratch : g; a.ld_src = D; a.alpha = alpha; a.mode = alpha_mode;
     a.self = h_src; a.ld_self = ld_src; a.out = dh_src; a.ld_out = ld_dh; a.aux1 = dalpha;
     a.D = D; a.flags = WGNN_FLAG_NO_MEAN; a.accumulate = accumulate;
     a.long_rows = reinterpret_cast<const int4*>(long_rows); a.n_long = n_long; a.partials = partials;

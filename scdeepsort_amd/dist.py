@@ -243,7 +243,7 @@ def all_reduce_grads(params) -> None:
 
 def sharded_train_step(params, weights_fn, feats_g, feats_c_local, labels_local, ops: LocalOps, n_layers: int,
                        optimizer, seeds_local: Optional[torch.Tensor] = None, dropout_masks=None, relu: bool = True,
-                       linear: Callable = torch.nn.functional.linear) -> float:
+                       linear: Callable = torch.nn.functional.linear, loss_sum: Optional[Callable] = None) -> float:
     """One full-batch data-parallel training step over cell shards (BASELINE cfg4).
 
     loss = CrossEntropyLoss(reduction='sum') over this rank's cells (train.py:36); because the loss is a SUM, adding
@@ -251,7 +251,8 @@ def sharded_train_step(params, weights_fn, feats_g, feats_c_local, labels_local,
     then applies the identical optimizer step.  Returns the global loss."""
     logits = sharded_forward(weights_fn(), None, feats_g, feats_c_local, ops, n_layers, gather_logits=False,
                              dropout_masks=dropout_masks, relu=relu, linear=linear, seeds_local=seeds_local)
-    loss = torch.nn.functional.cross_entropy(logits, labels_local, reduction="sum")
+    loss = loss_sum(logits, labels_local) if loss_sum is not None else \
+        torch.nn.functional.cross_entropy(logits, labels_local, reduction="sum")     # train.py:36
     optimizer.zero_grad()
     loss.backward()
     all_reduce_grads(params)

@@ -161,10 +161,11 @@ def agg_fwd(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, self_idx: int
 def agg_bwd_src(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, g: torch.Tensor,
                 h_src: Optional[torch.Tensor], dalpha: Optional[torch.Tensor] = None,
                 dh_src: Optional[torch.Tensor] = None, accumulate: bool = False,
-                dst_scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+                dst_scale: Optional[torch.Tensor] = None, prescaled: bool = False) -> torch.Tensor:
     """K2 ``wgnn_agg_bwd_src``: gradient w.r.t. the gathered rows (transposed SpMM);
     for SRC_IS_GENE also writes dalpha[0:n_src] = <h_src[s], T[s]>.  ``dst_scale`` replaces the per-destination
-    factor 1/(deg+1) (``csr.inv_deg``), e.g. ones for the backward of a plain weighted sum."""
+    factor 1/(deg+1) (``csr.inv_deg``), e.g. ones for the backward of a plain weighted sum.  ``prescaled``: ``g`` already
+    carries the per-destination factors (``agg_bwd_prepare``) - LDS-streamed route only."""
     dev = _require_cuda(g, h_src, alpha)
     inv_deg = csr.inv_deg if dst_scale is None else dst_scale.float().contiguous()
     t = csr.transposed()
@@ -182,19 +183,24 @@ def agg_bwd_src(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, g: torch.
     if TILED_MIN_WORK is not None and D <= 256 and csr.nnz * D >= TILED_MIN_WORK and csr.ell_cnt is None:
         # K2t: LDS-streamed kernel over the transposed structure; per-destination factors folded into g once
         tp = t.tile_plan(tiled_block_rows(D))
-        scale = inv_deg if mode != DST_IS_GENE else inv_deg * alpha[: csr.n_rows]
         g = g.contiguous()
-        scratch = torch.empty_like(g)
+        if prescaled:
+            scale, scratch = None, None
+        else:
+            scale = (inv_deg if mode != DST_IS_GENE else inv_deg * alpha[: csr.n_rows]).contiguous()
+            scratch = torch.empty_like(g)
         part = torch.empty(tp.n_partials * D, dtype=torch.float32, device=dev) if tp.n_partials else None
         n_long = tp.long_rows.shape[0]
         rc = _lib.call(dev, "wgnn_agg_bwd_src_tiled",
-            _ptr(alpha), mode, _ptr(scale.contiguous()), _ptr(g), g.shape[0], _ptr(scratch),
+            _ptr(alpha), mode, _ptr(scale), _ptr(g), g.shape[0], _ptr(scratch),
             _ptr(h_src), h_src.stride(0) if h_src is not None else 0, _ptr(dh_src), dh_src.stride(0), _ptr(dalpha),
             int(accumulate), t.n_rows, D, _ptr(tp.entries), _ptr(tp.seg_ptr), tp.nblk_max, tp.block_rows,
             _ptr(tp.items), _ptr(tp.hdr), tp.n_tiles, _ptr(tp.long_rows) if n_long else None, n_long,
             _ptr(part), tp.n_partials, _stream(dev))
         _lib.check(rc, "wgnn_agg_bwd_src_tiled")
         return dh_src
+    if prescaled:
+        raise WgnnError("prescaled gradient rows are an input of the LDS-streamed K2t only")
     part = _partials(t.plan, D, dev)
     rc = _lib.call(dev, "wgnn_agg_bwd_src",
         _ptr(t.rowptr), _ptr(t.col), _ptr(t.val), _ptr(alpha), mode, _ptr(inv_deg),
@@ -280,6 +286,90 @@ NARROW_LDS_ROWS = True       # round 4: LDS rows of the flat tile kernel are D*4
 def flat_lds_row_bytes(D: int) -> int:
     """LDS row stride of ``agg_tiled_flat4`` (csrc/wgnn_tiled.hip::flat_lds_row_bytes)."""
     return min(1024, -(-D * 4 // 256) * 256)
+
+
+FUSED_BWD_GLUE = True        # round 4: one wgnn_agg_bwd_prepare launch instead of the ~8 framework elementwise / reduce launches between
+                             # the upstream gradient and K2t (A/B switch)
+
+
+def agg_bwd_prepare(gout: torch.Tensor, out: Optional[torch.Tensor], inv_deg: Optional[torch.Tensor],
+                    alpha: Optional[torch.Tensor], mode: int, self_idx: int, *, want_scaled: bool = True,
+                    h_self: Optional[torch.Tensor] = None, want_dh_self: bool = False,
+                    neigh_sum: Optional[torch.Tensor] = None, want_dself: bool = False, want_dbias: bool = False) -> dict:
+    """``wgnn_agg_bwd_prepare``: from the upstream gradient ``gout`` [R, D] of one aggregation pass (and the saved forward
+    output ``out`` for the ReLU mask) in ONE read: ``g_scaled`` (K2t's pre-scaled source table), ``dh_self``, ``dalpha_row``
+    (needs ``neigh_sum``), ``dself_row`` (needs ``h_self``) and ``dbias`` - whichever are asked for."""
+    import ctypes as C
+    dev = _require_cuda(gout, out, inv_deg, alpha, h_self, neigh_sum)
+    gout = _rowmajor(gout.float())
+    R, D = gout.shape
+    if out is not None:
+        out = _rowmajor(out.float())
+    if h_self is not None:
+        h_self = _rowmajor(h_self.float())
+    if neigh_sum is not None:
+        neigh_sum = neigh_sum.float().contiguous()
+    if alpha is not None:
+        alpha = alpha.reshape(-1).float().contiguous()
+    if inv_deg is not None:
+        inv_deg = inv_deg.float().contiguous()
+    res = {"g_scaled": torch.empty((R, D), dtype=torch.float32, device=dev) if want_scaled else None,
+           "dh_self": torch.empty((R, D), dtype=torch.float32, device=dev) if want_dh_self else None,
+           "dalpha_row": torch.empty(R, dtype=torch.float32, device=dev) if neigh_sum is not None else None,
+           "dself_row": torch.empty(R, dtype=torch.float32, device=dev) if (want_dself and h_self is not None) else None,
+           "dbias": torch.empty(D, dtype=torch.float32, device=dev) if want_dbias else None}
+    ws, nf = None, C.c_int64(0)
+    if want_dbias:
+        _lib.check(_lib.lib().wgnn_agg_bwd_prepare_workspace(R, D, C.addressof(nf)), "wgnn_agg_bwd_prepare_workspace")
+        ws = torch.empty(max(1, nf.value), dtype=torch.float32, device=dev)
+    need_self = res["dh_self"] is not None or res["dself_row"] is not None
+    rc = _lib.call(dev, "wgnn_agg_bwd_prepare", _ptr(gout), gout.stride(0), _ptr(out), out.stride(0) if out is not None else 0,
+                   _ptr(inv_deg), _ptr(alpha), mode, self_idx, _ptr(res["g_scaled"]),
+                   _ptr(h_self) if need_self else None, h_self.stride(0) if (need_self and h_self is not None) else 0,
+                   _ptr(res["dh_self"]), D, _ptr(neigh_sum), _ptr(res["dalpha_row"]), _ptr(res["dself_row"]), _ptr(res["dbias"]),
+                   R, D, _ptr(ws), nf.value, _stream(dev))
+    _lib.check(rc, "wgnn_agg_bwd_prepare")
+    return res
+
+
+class _CrossEntropySum(torch.autograd.Function):
+    """``CrossEntropyLoss(reduction='sum')`` (train.py:36) through ``wgnn_ce_sum_fwd_bwd``: loss and softmax - onehot from one
+    read of the logits (the framework's log_softmax / nll_loss pair costs ~0.2 ms per step at 1e5 rows x 16 classes)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        import ctypes as C
+        dev = _require_cuda(logits, labels)
+        x = logits.float()
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        y = labels.to(torch.int64).contiguous()
+        n, c = x.shape
+        nf = C.c_int64(0)
+        _lib.check(_lib.lib().wgnn_ce_sum_workspace(n, C.addressof(nf)), "wgnn_ce_sum_workspace")
+        ws = torch.empty(max(1, nf.value), dtype=torch.float32, device=dev)
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        d = torch.empty((n, c), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        rc = _lib.call(dev, "wgnn_ce_sum_fwd_bwd", _ptr(x), x.stride(0), _ptr(y), n, c, _ptr(loss), _ptr(d), c, _ptr(ws), nf.value,
+                       _stream(dev))
+        _lib.check(rc, "wgnn_ce_sum_fwd_bwd")
+        ctx.save_for_backward(d)
+        ctx.in_dtype = logits.dtype
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (d,) = ctx.saved_tensors
+        return (d * g).to(ctx.in_dtype), None
+
+
+def cross_entropy_sum(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+    """``F.cross_entropy(logits, labels, reduction='sum')`` on the GPU path (2-D logits, class-index labels)."""
+    if logits.dim() != 2 or labels.dim() != 1 or labels.shape[0] != logits.shape[0]:
+        raise ValueError("cross_entropy_sum: logits [n, classes], labels [n]")
+    if logits.shape[0] == 0:
+        return logits.sum() * 0.0
+    return _CrossEntropySum.apply(logits, labels)
 
 
 def tiled_block_rows(D: int) -> int:
@@ -371,6 +461,33 @@ class WeightedMeanAggregate(torch.autograd.Function):
         h_src, h_self, alpha, out, row_ids, nsum = ctx.saved_tensors
         csr: AggCsr = ctx.csr
         mode, self_idx = ctx.mode, ctx.self_idx
+        Dg = gout.shape[1]
+        if (FUSED_BWD_GLUE and row_ids is None and gout.is_cuda and Dg % 4 == 0 and tiled_kernel_serves(csr, Dg)
+                and (mode != DST_IS_GENE or nsum is not None or not ctx.needs_input_grad[2])
+                and (h_self is None or h_self.dtype == torch.float32) and h_src.dtype == torch.float32):
+            # full pass on the LDS-streamed route: ONE fused launch turns the upstream gradient into K2t's pre-scaled source
+            # table, the self-row gradient, the alpha row dots and the bias gradient
+            a = alpha.reshape(-1)
+            want_dalpha = ctx.needs_input_grad[2] and mode != NO_ALPHA
+            want_src_dalpha = want_dalpha and mode == SRC_IS_GENE
+            need_k2 = ctx.needs_input_grad[0] or want_src_dalpha
+            res = agg_bwd_prepare(gout, out if ctx.relu else None, csr.inv_deg, a if mode != NO_ALPHA else None, mode, self_idx,
+                                  want_scaled=need_k2, h_self=h_self, want_dh_self=h_self is not None and ctx.needs_input_grad[1],
+                                  neigh_sum=nsum if (want_dalpha and mode == DST_IS_GENE) else None,
+                                  want_dself=want_dalpha and h_self is not None, want_dbias=ctx.has_bias)
+            dalpha = torch.zeros_like(a) if ctx.needs_input_grad[2] else None
+            dh_src = None
+            if need_k2:
+                dh_src = agg_bwd_src(csr, a if mode != NO_ALPHA else None, mode, res["g_scaled"], h_src if want_src_dalpha else None,
+                                     dalpha if want_src_dalpha else None, prescaled=True)
+                dh_src = dh_src.to(h_src.dtype) if ctx.needs_input_grad[0] else None
+            if dalpha is not None:
+                if res["dalpha_row"] is not None:
+                    dalpha[: csr.n_rows] += res["dalpha_row"]
+                if res["dself_row"] is not None:
+                    dalpha[self_idx] += res["dself_row"].sum()
+                dalpha = dalpha.reshape(alpha.shape)
+            return dh_src, res["dh_self"], dalpha, res["dbias"], None, None, None, None, None, None
         g = gout.float()
         if ctx.relu:
             g = g * (out > 0)

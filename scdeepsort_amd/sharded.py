@@ -15,7 +15,7 @@ from . import dist as D
 from ._lib import DST_IS_GENE, NO_ALPHA, SRC_IS_GENE
 from .gnn import GNN, _is_relu, pad_width
 from .graph import AggCsr, CellGeneGraph, _normalize_on_device, build_plan
-from .ops import agg_fwd, linear as _linear, linear_act, weighted_mean_aggregate, weighted_sum
+from .ops import agg_fwd, cross_entropy_sum, linear as _linear, linear_act, weighted_mean_aggregate, weighted_sum
 
 
 class ShardedWgnn:
@@ -179,7 +179,8 @@ class ShardedWgnn:
         if dropout_masks is None:
             dropout_masks = self.dropout_masks(feats_g, feats_c_local)
         return D.sharded_train_step(list(self.model.parameters()), self._weights, feats_g, feats_c_local, labels_local,
-                                    self._ops(), self.model.n_layers, optimizer, seeds_local, dropout_masks, self.relu, _linear)
+                                    self._ops(), self.model.n_layers, optimizer, seeds_local, dropout_masks, self.relu, _linear,
+                                    cross_entropy_sum)
 
     def forward(self, feats_g: torch.Tensor, feats_c_local: torch.Tensor, gather_logits: bool = True,
                 async_gather: bool = False) -> torch.Tensor:

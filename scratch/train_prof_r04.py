@@ -11,9 +11,14 @@ g = sda.CellGeneGraph.from_device_csr(rp, col, val, G)
 torch.manual_seed(1)
 m = sda.GNN(cfg.dense_dim, cfg.hidden, cfg.n_classes, 2, G, activation=F.relu, dropout=float(os.environ.get('DROPOUT', '0.1'))).to(dev)
 feats = S.synth_features(G + C, cfg.dense_dim, device=dev); y = torch.arange(C, device=dev) % cfg.n_classes
-opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-4)
+from scdeepsort_amd import ops
+FUSED = os.environ.get('FUSED', '1') == '1'           # round-4 glue: fused CE-sum, fused backward glue, fused Adam
+ops.FUSED_BWD_GLUE = FUSED
+opt = torch.optim.Adam(m.parameters(), lr=1e-3, weight_decay=5e-4, fused=FUSED)
 def step():
-    loss = F.cross_entropy(m(g, feats), y, reduction='sum'); opt.zero_grad(); loss.backward(); opt.step(); return loss
+    logits = m(g, feats)
+    loss = sda.cross_entropy_sum(logits, y) if FUSED else F.cross_entropy(logits, y, reduction='sum')
+    opt.zero_grad(); loss.backward(); opt.step(); return loss
 for _ in range(3): step()
 torch.cuda.synchronize()
 n = int(os.environ.get('STEPS', '10'))
@@ -21,4 +26,4 @@ e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=Tr
 e0.record()
 for _ in range(n): loss = step()
 e1.record(); torch.cuda.synchronize()
-print(f"full-batch cfg3 training step: {e0.elapsed_time(e1) / n:.3f} ms  (loss {float(loss):.1f})")
+print(f"FUSED={int(FUSED)} full-batch cfg3 training step: {e0.elapsed_time(e1) / n:.3f} ms  (loss {float(loss):.1f})")

@@ -1820,3 +1820,89 @@ def test_tile_kernel_packed_lds_rows_at_full_block_height(D, direction):
         ops.TILED_MIN_WORK = saved
     for a_, b_ in zip(res[None], res[1]):
         np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.parametrize("n,c", [(1, 2), (7, 5), (1000, 16), (100_003, 16), (513, 33)])
+def test_cross_entropy_sum_kernel_matches_torch(n, c):
+    """`ops.cross_entropy_sum` = CrossEntropyLoss(reduction='sum') (train.py:36): loss and dloss/dlogits from one read of the
+    logits (wgnn_ce_sum_fwd_bwd), against torch in fp64; deterministic run to run."""
+    from scdeepsort_amd import ops
+    gen = torch.Generator(device=DEV).manual_seed(n + c)
+    x = (3.0 * torch.randn(n, c, generator=gen, device=DEV)).requires_grad_(True)
+    y = torch.randint(0, c, (n,), generator=gen, device=DEV)
+    loss = ops.cross_entropy_sum(x, y)
+    (2.0 * loss).backward()
+    x64 = x.detach().double().requires_grad_(True)
+    ref = F.cross_entropy(x64, y, reduction="sum")
+    (2.0 * ref).backward()
+    assert abs(loss.item() - ref.item()) < 2e-6 * max(1.0, abs(ref.item())) * max(1.0, n ** 0.5 / 30)
+    np.testing.assert_allclose(x.grad.cpu().numpy(), x64.grad.cpu().numpy(), atol=2e-6)
+    assert ops.cross_entropy_sum(x.detach(), y).item() == ops.cross_entropy_sum(x.detach(), y).item()
+    assert ops.cross_entropy_sum(x[:0], y[:0]).item() == 0.0
+
+
+@pytest.mark.parametrize("mode", ["cells", "genes", "plain"])
+@pytest.mark.parametrize("D", [4, 64, 200, 256, 400])
+def test_agg_bwd_prepare_matches_the_framework_glue(mode, D):
+    """wgnn_agg_bwd_prepare: ReLU mask, K2t's pre-scaled source rows, the self-row gradient, the alpha row dots and the bias
+    gradient from ONE read of the upstream gradient - each output against the torch expression it replaces."""
+    from scdeepsort_amd import ops
+    R = 777
+    gen = torch.Generator(device=DEV).manual_seed(D)
+    gout = torch.randn(R, D, generator=gen, device=DEV); out = torch.randn(R, D, generator=gen, device=DEV)
+    hs = torch.randn(R, D, generator=gen, device=DEV); ns = torch.randn(R, D, generator=gen, device=DEV)
+    invd = torch.rand(R, generator=gen, device=DEV) + 0.1
+    alpha = torch.rand(R + 2, generator=gen, device=DEV) + 0.5
+    m = {"cells": sda.SRC_IS_GENE, "genes": sda.DST_IS_GENE, "plain": sda.NO_ALPHA}[mode]
+    self_idx = R + 1 if mode == "cells" else R
+    for relu in (True, False):
+        res = ops.agg_bwd_prepare(gout, out if relu else None, invd, None if mode == "plain" else alpha, m, self_idx,
+                                  want_scaled=True, h_self=hs, want_dh_self=True, neigh_sum=ns if mode == "genes" else None,
+                                  want_dself=mode != "plain", want_dbias=True)
+        g = (gout * (out > 0)) if relu else gout
+        f = invd * (alpha[:R] if mode == "genes" else 1.0)
+        a_self = 1.0 if mode == "plain" else alpha[self_idx]
+        np.testing.assert_allclose(res["g_scaled"].cpu().numpy(), (g * f[:, None]).cpu().numpy(), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(res["dh_self"].cpu().numpy(), (g * (a_self * invd)[:, None]).cpu().numpy(), rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(res["dbias"].cpu().numpy(), g.double().sum(0).cpu().numpy(), rtol=1e-5, atol=2e-4)
+        if mode == "genes":
+            np.testing.assert_allclose(res["dalpha_row"].cpu().numpy(), ((g.double() * ns.double()).sum(1) * invd).cpu().numpy(), rtol=1e-5, atol=1e-4)
+        else:
+            assert res["dalpha_row"] is None
+        if mode != "plain":
+            np.testing.assert_allclose(res["dself_row"].cpu().numpy(), ((g.double() * hs.double()).sum(1) * invd).cpu().numpy(), rtol=1e-5, atol=1e-4)
+    only = ops.agg_bwd_prepare(gout, None, None, None, sda.NO_ALPHA, 0, want_scaled=True)       # nothing optional: a copy
+    assert torch.equal(only["g_scaled"], gout) and all(only[k] is None for k in ("dh_self", "dalpha_row", "dself_row", "dbias"))
+
+
+@pytest.mark.parametrize("order", ["auto", "project_first", "aggregate_first"])
+def test_fused_backward_glue_gives_the_same_gradients(order, monkeypatch):
+    """Full-batch training step on the LDS-streamed route with the round-4 glue (one wgnn_agg_bwd_prepare launch per pass,
+    K2t on pre-scaled rows, fused CE) against the framework glue of before and the autograd oracle."""
+    from scdeepsort_amd import ops
+    c = small_case(cells=150, genes=70, dim=24, hidden=20, n_classes=4, seed=21, test_cells=0)
+    sd = O.init_params(24, 20, 4, 2, 70, seed=8)
+    rg = O.build_reference_graph(c["expr"])
+    seeds = np.arange(70, 70 + 150)
+    labels = torch.arange(150) % 4
+    loss, grads, _ = O.loss_and_grads(sd, rg, torch.from_numpy(c["feats"]), seeds, labels, 2)
+    g = sda.CellGeneGraph.from_expression(c["expr"], device=DEV)
+    monkeypatch.setattr(ops, "TILED_MIN_WORK", 1)
+    got = {}
+    for fused in (True, False):
+        monkeypatch.setattr(ops, "FUSED_BWD_GLUE", fused)
+        calls = []
+        real = ops.agg_bwd_prepare
+        monkeypatch.setattr(ops, "agg_bwd_prepare", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+        m = make_model(sd, 24, 20, 4, 2, 70, order)
+        logits = m(g, dev(c["feats"]))
+        l = ops.cross_entropy_sum(logits, labels.to(DEV)) if fused else F.cross_entropy(logits, labels.to(DEV), reduction="sum")
+        l.backward()
+        monkeypatch.setattr(ops, "agg_bwd_prepare", real)
+        assert (len(calls) == 3) == fused, calls                     # L2 cells, L1 cells, L1 genes
+        assert l.item() == pytest.approx(float(loss), rel=1e-5)
+        got[fused] = {k: p.grad.clone() for k, p in m.named_parameters()}
+        for k, p in m.named_parameters():
+            np.testing.assert_allclose(p.grad.cpu().numpy(), grads[k].numpy(), atol=2e-4, rtol=1e-3, err_msg=f"{k} fused={fused}")
+    for k in got[True]:
+        assert (got[True][k] - got[False][k]).abs().max().item() < 2e-5 * max(1.0, got[False][k].abs().max().item()), k
