@@ -53,7 +53,7 @@ def pad_width(nnz: int, H: int) -> int:
     hidden_dim = 200 (train.py:137) moves 200-float rows.  ``ops.PAD_NARROW_TO_256`` restores the old behaviour for
     A/B timing; ``nnz`` (max over ranks in a sharded job, so that every rank decides alike) only matters then."""
     from . import ops
-    if ops.PAD_NARROW_TO_256 and H < 256 and ops.TILED_MIN_WORK is not None and nnz * H >= ops.TILED_MIN_WORK:
+    if ops.PAD_NARROW_TO_256 and H < 256 and ops.TILED_MIN_WORK is not None and nnz * max(H, 128) >= ops.TILED_MIN_WORK:
         return 256
     return -(-H // 4) * 4
 
@@ -137,8 +137,7 @@ class GNN(nn.Module):
             # when the cells<-genes pass will run LDS-streamed (it needs alpha[g] * P_g[g] as its source table) and nothing
             # here is differentiated, ONE kernel writes both P_g and its alpha-folded copy (no scale_rows launch)
             p_g_scaled = None
-            tiled_cells = (_ops.TILED_MIN_WORK is not None and Hp <= 256 and g.cg.nnz * Hp >= _ops.TILED_MIN_WORK
-                           and g.cg.ell_cnt is None and not torch.is_grad_enabled()
+            tiled_cells = (_ops.tiled_kernel_serves(g.cg, Hp) and not torch.is_grad_enabled()
                            and (cell_rows is None or cell_rows.shape[0] >= _ops.SEED_FULL_PASS_MIN_FRAC * g.cg.n_rows))
             if tiled_cells and _ops.use_wgnn_linear(h_g, W, dual=True):
                 p_g, p_g_scaled = _ops.linear_fwd(h_g, W, row_scale=self.alpha.reshape(-1)[:G])
@@ -204,7 +203,7 @@ class GNN(nn.Module):
             if seeds.step != 1 or seeds.start < G or seeds.stop > G + g.num_cells:
                 raise ValueError("a seed range must be a step-1 range of cell node ids")
             H0 = self.layers[0].fc_neigh.weight.shape[0]
-            big = (_ops.TILED_MIN_WORK is not None and g.cg.nnz * min(H0, 256) >= _ops.TILED_MIN_WORK
+            big = (_ops.tiled_kernel_serves(g.cg, -(-min(H0, 256) // 4) * 4)
                    and len(seeds) >= _ops.SEED_FULL_PASS_MIN_FRAC * g.num_cells)
             if big:
                 return self.embed(g, features, None)[seeds.start - G: seeds.stop - G]

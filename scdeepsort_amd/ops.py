@@ -54,14 +54,20 @@ SAVE_NEIGH_SUM = True               # training: the forward of gene rows saves i
 SEED_BLOCK_MAX_CAP = 12_000_000     # B x longest row above which a seed batch's backward walks the full transposed graph instead
                                     # (sorting the padded block costs ~0.05 ms per million slots; the full K2t pass 1.2 ms at cfg3)
 PAD_NARROW_TO_256 = False           # round-1 behaviour (hidden < 256 carried as 256 zero-padded columns); kept for A/B timing
-TILED_MIN_WORK = int(__import__("os").environ.get("WGNN_TILED_MIN_WORK", 500_000_000))   # nnz*D above which the LDS-streamed kernels win (measured crossover: ~2 M edges at D = 256)
+# nnz * max(D, 128) above which the LDS-streamed kernels take a pass.  The tile kernel's time hardly depends on D (it is bound
+# by per-edge instruction issue), the row-wave kernel's gathers scale with it: at BASELINE cfg2's 2.0 M edges a pass costs
+# 60 / 59 us tiled against 62 / 71 us row-wave at D = 128 and 62 / 61 against 100 / 129 us at D = 200 (round 4,
+# scratch/narrow_rows.py) - rounds 1-3 used 5e8 (~2 M edges at D = 256), which left cfg2 and every hidden-200 graph of
+# that size on the row-wave kernel.
+TILED_MIN_WORK = int(__import__("os").environ.get("WGNN_TILED_MIN_WORK", 250_000_000))
 SEED_FULL_PASS_MIN_FRAC = 0.2       # a seed set of at least this share of the rows of a tile-kernel operand runs the FULL LDS-streamed
                                     # pass and gathers its rows (row-wave K1 costs ~5x per edge: 6.2 vs 1.19 ms for all of cfg3)
 
 
 def tiled_kernel_serves(csr: AggCsr, D: int) -> bool:
     """True when a FULL pass over ``csr`` at width ``D`` is dispatched to the LDS-streamed kernel (K1t)."""
-    return TILED_MIN_WORK is not None and D <= 256 and D % 4 == 0 and csr.nnz * D >= TILED_MIN_WORK and csr.ell_cnt is None
+    return (TILED_MIN_WORK is not None and D <= 256 and D % 4 == 0 and csr.nnz * max(D, 128) >= TILED_MIN_WORK
+            and csr.ell_cnt is None)
 
 
 def will_run_tiled(csr: AggCsr, D: int, n_seed_rows: Optional[int] = None) -> bool:
@@ -180,7 +186,7 @@ def agg_bwd_src(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, g: torch.
         h_src = _rowmajor(h_src.float())
     if alpha is not None:
         alpha = alpha.reshape(-1).float().contiguous()
-    if TILED_MIN_WORK is not None and D <= 256 and csr.nnz * D >= TILED_MIN_WORK and csr.ell_cnt is None:
+    if tiled_kernel_serves(csr, D):
         # K2t: LDS-streamed kernel over the transposed structure; per-destination factors folded into g once
         tp = t.tile_plan(tiled_block_rows(D))
         g = g.contiguous()
@@ -255,8 +261,7 @@ def agg_bwd_alpha(csr: AggCsr, g: torch.Tensor, h_src: torch.Tensor, h_self: Opt
         h_self = _rowmajor(h_self.float())
     d_row = torch.empty(n_out, dtype=torch.float32, device=dev)
     d_self = torch.empty(n_out, dtype=torch.float32, device=dev) if h_self is not None else None
-    if (TILED_MIN_WORK is not None and row_ids is None and D <= 256 and csr.nnz * D >= TILED_MIN_WORK
-            and csr.ell_cnt is None):
+    if row_ids is None and tiled_kernel_serves(csr, D):
         tp = csr.tile_plan(tiled_block_rows(D))                                   # K3t
         h_src = h_src.contiguous()
         part = torch.empty(tp.n_partials * D, dtype=torch.float32, device=dev) if tp.n_partials else None

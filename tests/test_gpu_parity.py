@@ -32,7 +32,7 @@ def test_library_loaded_and_gpu_present():
     assert torch.cuda.is_available()
     assert "gfx950" in torch.cuda.get_device_properties(0).gcnArchName
     from scdeepsort_amd import _lib
-    assert _lib.lib().wgnn_version() == 201
+    assert _lib.lib().wgnn_version() >= _lib.ABI_MIN and _lib.lib().wgnn_version() // 100 == _lib.ABI_MAJOR
 
 
 def test_kat_2x2_on_gpu():
