@@ -40,8 +40,11 @@ constexpr unsigned kDbgNoFill = 1u << 16, kDbgNoCompute = 1u << 17, kDbgNoBarrie
 constexpr unsigned kDbgSkipHubShift = 21;          // bits 21..23 = n: skip the entry pipeline of the first 2n LDS blocks (prices a dense treatment of hub sources)
 constexpr unsigned kDbgFillToVgpr = 1u << 20;      // the fill's loads go to scratch VGPRs instead of LDS: same VMEM issue / L2 traffic, no LDS writes
 
-// LDS row stride of agg_tiled_flat4 (host and device): D*4 bytes rounded up to a multiple of 256, at most 1 KiB
-__host__ __device__ inline int flat_lds_row_bytes(int D) { const int b = (D * 4 + 255) & ~255; return b < 1024 ? b : 1024; }
+// LDS row stride of agg_tiled_flat4 (host and device): 256 B (D <= 64), 512 B (D <= 128) or 1 KiB.  A power of two that
+// covers the row: the per-lane LDS address is {row address} OR {16 * lane} (one v_and_or_b32 per entry), which only equals
+// the sum while the lanes that carry data (16 * lane < D * 4 <= stride) stay below the row address's lowest set bit - a
+// 768-byte stride for D <= 192 would pack closer but breaks exactly that (built and caught by the parity tests).
+__host__ __device__ inline int flat_lds_row_bytes(int D) { return D <= 64 ? 256 : (D <= 128 ? 512 : 1024); }
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -216,10 +219,10 @@ template <typename TOut, int EPI, bool DBG>
 __global__ void __launch_bounds__(kTW * 64) __attribute__((amdgpu_num_vgpr(16)))
 agg_tiled_flat4(const KArgs a, const TArgs t) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // LDS row stride: the row's bytes rounded up to a multiple of 256 (512 B at D = 128, 1 KiB for D > 192), so that an LDS
-    // row address has zero low byte and {row address (bits 8..17) | 4*slot (bits 2..5)} packs into one dword.  Rounds 2-3
-    // kept 1 KiB whatever D was: at D = 128 half of every LDS block was dead (78 rows per block where 156 fit - twice the
-    // barriers and pipeline warm-ups per edge).
+    // LDS row stride: 256 B / 512 B / 1 KiB, the power of two that covers the row (flat_lds_row_bytes), so that an LDS row
+    // address has zero low byte and {row address (bits 8..17) | 4*slot (bits 2..5)} packs into one dword.  Rounds 2-3 kept
+    // 1 KiB whatever D was: at D = 128 half of every LDS block was dead (78 rows per block where 156 fit).  Packing halves
+    // the barriers per edge - and measured neutral (round 4, scratch/narrow_rows.py): the kernel is not bound by them.
     const int row_bytes = flat_lds_row_bytes(a.D);
     const int g_row = a.D * (int)sizeof(float);          // global row stride: D <= 256 floats (lanes >= D/4 carry nothing)
     const int n4 = a.D >> 2;                             // lanes that move 16 B of a row in the global->LDS DMA
@@ -518,7 +521,7 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
     }                                                    // ---- epilogue scope
 }
 
-// LDS bytes of one launch: the flat kernel's LDS rows are D*4 bytes rounded up to 256 (+ the per-wave weight strips)
+// LDS bytes of one launch: the flat kernel's LDS rows are 256 / 512 / 1024 bytes (+ the per-wave weight strips)
 inline bool use_flat(int D, unsigned flags) { return D <= 256 && !(flags & (1u << 19)); }   // bit 19: force the generic kernel (A/B)
 inline long tiled_lds_bytes(int D, int block_rows, unsigned flags) {
     return use_flat(D, flags) ? 2L * block_rows * flat_lds_row_bytes(D) + kWStripBytes : 2L * block_rows * D * (long)sizeof(float);

@@ -284,13 +284,13 @@ def agg_bwd_alpha(csr: AggCsr, g: torch.Tensor, h_src: torch.Tensor, h_self: Opt
     return d_row, d_self
 
 
-NARROW_LDS_ROWS = True       # round 4: LDS rows of the flat tile kernel are D*4 bytes rounded up to 256 (False: 78-row blocks for
+NARROW_LDS_ROWS = True       # round 4: LDS rows of the flat tile kernel are 256 / 512 / 1024 bytes by width (False: 78-row blocks for
                              # every D, the round-2/3 geometry - the kernel itself always packs; kept for A/B timing)
 
 
 def flat_lds_row_bytes(D: int) -> int:
-    """LDS row stride of ``agg_tiled_flat4`` (csrc/wgnn_tiled.hip::flat_lds_row_bytes)."""
-    return min(1024, -(-D * 4 // 256) * 256)
+    """LDS row stride of ``agg_tiled_flat4`` (csrc/wgnn_tiled.hip::flat_lds_row_bytes): the power of two covering a row."""
+    return 256 if D <= 64 else (512 if D <= 128 else 1024)
 
 
 FUSED_BWD_GLUE = True        # round 4: one wgnn_agg_bwd_prepare launch instead of the ~8 framework elementwise / reduce launches between
@@ -379,9 +379,11 @@ def cross_entropy_sum(logits: torch.Tensor, labels: torch.Tensor) -> torch.Tenso
 
 def tiled_block_rows(D: int) -> int:
     """Source rows per LDS block of the tile kernels: two buffers + the 4 KiB of per-wave weight strips fill the 160 KiB of
-    a CU (measured best at D = 256: 78 x 1 KiB x 2).  Narrower rows pack closer (row stride = D*4 bytes rounded up to 256):
-    156 rows per block at D <= 128, 104 at D <= 192 - half / two thirds of the per-block barriers and pipeline warm-ups
-    per edge.  An entry names its source row inside a block with 8 bits, so a block holds at most 255 rows (D <= 64)."""
+    a CU (measured best at D = 256: 78 x 1 KiB x 2).  Narrower rows pack closer (row stride 512 B at D <= 128, 256 B at
+    D <= 64): 156 / 255 rows per block - half the per-block barriers and pipeline warm-ups per edge, which measured
+    NEUTRAL (cfg2 60.9 / 58.8 -> 60.0 / 59.5 us per pass, cfg3 at D = 128 1.050 / 0.956 -> 1.039 / 0.972 ms: the kernel is
+    bound by per-edge issue latency, not by its barriers).  An entry names its source row inside a block with 8 bits, so a
+    block holds at most 255 rows."""
     if not NARROW_LDS_ROWS:
         return 78
     return min(255, (160 * 1024 - 4096) // 2 // flat_lds_row_bytes(D))

@@ -217,7 +217,16 @@ def test_full_size_properties_cfg2():
     assert torch.equal(z1, f(h1)) and torch.equal(y1, fg(h1))                    # deterministic (no atomics)
     ids = torch.randperm(C, device=DEV)[:777]
     sub = sda.agg_fwd(g.cg, alpha, sda.SRC_IS_GENE, G + 1, h1[:G], h1[G:], row_ids=ids)
-    assert torch.equal(sub, z1[ids])
+    # since round 4 a cfg2-size full pass runs LDS-streamed (ops.TILED_MIN_WORK): the seeds' rows (row-wave kernel) agree with
+    # it to rounding, and bit for bit with the row-wave kernel's own full pass
+    from scdeepsort_amd import ops
+    assert ops.tiled_kernel_serves(g.cg, cfg.hidden)
+    assert (sub - z1[ids]).abs().max().item() < 1e-5
+    saved, ops.TILED_MIN_WORK = ops.TILED_MIN_WORK, None
+    try:
+        assert torch.equal(sub, f(h1)[ids])
+    finally:
+        ops.TILED_MIN_WORK = saved
     # oracle on the same graph (CPU, seconds at this size)
     expr = S.to_scipy(rp, col, val, G)
     cg = O.build_csr_graph(expr)
@@ -1771,14 +1780,14 @@ def test_sharded_branch_folds_alpha_in_genes_finish(monkeypatch):
 @pytest.mark.parametrize("D", [32, 64, 100, 128, 132, 192, 200, 256])
 @pytest.mark.parametrize("direction", ["cells", "genes"])
 def test_tile_kernel_packed_lds_rows_at_full_block_height(D, direction):
-    """Round 4: the flat tile kernel's LDS rows are D*4 bytes rounded up to 256 (512 B at D = 128 instead of a 1 KiB slot),
-    and `ops.tiled_block_rows(D)` fills the 160 KiB of a CU with them: 255 / 156 / 104 / 78 source rows per block.  Every
+    """Round 4: the flat tile kernel's LDS rows are 256 / 512 / 1024 bytes by width (512 B at D = 128 instead of a 1 KiB slot),
+    and `ops.tiled_block_rows(D)` fills the 160 KiB of a CU with them: 255 / 156 / 78 source rows per block.  Every
     stride at its full block height (several blocks per tile, column splits, loader wave, shared pairs), forward and the
     two backward entries, against the oracle / the row-wave kernels."""
     from scdeepsort_amd.graph import build_tile_plan
     from scdeepsort_amd import ops
     kb = ops.tiled_block_rows(D)
-    assert kb == {256: 255, 512: 156, 768: 104, 1024: 78}[ops.flat_lds_row_bytes(D)]
+    assert kb == {256: 255, 512: 156, 1024: 78}[ops.flat_lds_row_bytes(D)]
     assert 2 * kb * ops.flat_lds_row_bytes(D) + 4096 <= 160 * 1024
     c = small_case(cells=900, genes=640, dim=D, seed=D + 3, density=0.2, test_cells=40)
     g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
@@ -1906,3 +1915,76 @@ def test_fused_backward_glue_gives_the_same_gradients(order, monkeypatch):
             np.testing.assert_allclose(p.grad.cpu().numpy(), grads[k].numpy(), atol=2e-4, rtol=1e-3, err_msg=f"{k} fused={fused}")
     for k in got[True]:
         assert (got[True][k] - got[False][k]).abs().max().item() < 2e-5 * max(1.0, got[False][k].abs().max().item()), k
+
+
+def test_full_size_properties_cfg5():
+    """BASELINE cfg5 at FULL size on one GPU (764,741 cells x 20,000 genes, ~6.1e8 non-zeros per direction - 28 % of the
+    2^31 offset range the plans index with -, fp16-STORED features): the 13-round tile geometry of the cells side and the
+    one-round column-split geometry of the gene side, driver-verified.  Size-independent properties of both passes
+    (linearity, determinism, a row sample against the row-wave kernel, hipSPARSE cross-check, the constant-feature
+    checksum), then the whole 2-layer forward on fp16-stored features against the same forward on their fp32 copies."""
+    from scdeepsort_amd import ops, synthetic as S
+    cfg = S.CONFIGS["cfg5"]
+    G, C, H = cfg.genes, cfg.cells, cfg.hidden
+    rp, col, val = S.synth_expression(C, G, cfg.density, device=DEV)
+    nnz = int(col.shape[0])
+    assert 5.5e8 < nnz < 2 ** 31
+    g = sda.CellGeneGraph.from_device_csr(rp, col, val, G)
+    del rp, col, val
+    alpha = torch.rand(G + 2, device=DEV) + 0.5
+    hg1, hc1 = S.synth_features(G, H, device=DEV), S.synth_features(C, H, seed=3, device=DEV)
+    hg2, hc2 = S.synth_features(G, H, seed=5, device=DEV), S.synth_features(C, H, seed=6, device=DEV)
+    ops.PROFILE = []
+    f = lambda a, b: sda.agg_fwd(g.cg, alpha, sda.SRC_IS_GENE, G + 1, a, b)
+    fg = lambda a, b: sda.agg_fwd(g.gc, alpha, sda.DST_IS_GENE, G, b, a)
+    z1, z2, z3 = f(hg1, hc1), f(hg2, hc2), f(2 * hg1 - 0.5 * hg2, 2 * hc1 - 0.5 * hc2)
+    y1, y2, y3 = fg(hg1, hc1), fg(hg2, hc2), fg(2 * hg1 - 0.5 * hg2, 2 * hc1 - 0.5 * hc2)
+    kernels = {dict(zip(t[::2], t[1::2]))["kernel"] for t, _, _ in ops.PROFILE}
+    ops.PROFILE = None
+    assert kernels == {"agg_tiled_flat4"}
+    tpc, tpg = list(g.cg._tile_plan.values())[0], list(g.gc._tile_plan.values())[0]
+    assert tpc.n_col_splits == 1 and tpc.n_row_tiles >= 12 * 256 and tpc.n_loaders == 1        # 13-14 rounds of <= 240-row tiles
+    assert tpg.n_row_tiles * tpg.n_col_splits <= 256 and tpg.n_col_splits >= 2 and tpg.n_partials > 0
+    assert int(tpc.entries.shape[0]) >= nnz and int(tpc.seg_ptr[-1]) == int(tpc.entries.shape[0])
+    assert (2 * z1 - 0.5 * z2 - z3).abs().max().item() < 1e-4
+    assert (2 * y1 - 0.5 * y2 - y3).abs().max().item() < 1e-4
+    del z2, z3, y2, y3, hg2, hc2
+    assert torch.equal(z1, f(hg1, hc1)) and torch.equal(y1, fg(hg1, hc1))          # deterministic (no atomics)
+    ids = torch.randperm(C, device=DEV)[:1000]
+    sub = sda.agg_fwd(g.cg, alpha, sda.SRC_IS_GENE, G + 1, hg1, hc1, row_ids=ids)    # row-wave kernel (K1)
+    assert (sub - z1[ids]).abs().max().item() < 1e-4
+    gids = torch.randperm(G, device=DEV)[:200]
+    subg = sda.agg_fwd(g.gc, alpha, sda.DST_IS_GENE, G, hc1, hg1, row_ids=gids)
+    assert (subg - y1[gids]).abs().max().item() < 1e-4
+    # independent formulation: torch's CSR SpMM (hipSPARSE) over the whole operand, compared on a row sample
+    A_cg = torch.sparse_csr_tensor(g.cg.rowptr.long(), g.cg.col.long(), g.cg.val, size=(C, G))
+    ref_c = (torch.sparse.mm(A_cg, alpha[:G, None] * hg1) + alpha[G + 1] * hc1) * g.cg.inv_deg[:, None]
+    samp = torch.randperm(C, device=DEV)[:50_000]
+    assert (ref_c[samp] - z1[samp]).abs().max().item() < 1e-4
+    del A_cg, ref_c
+    # checksum of checksums: constant features
+    ones_g, ones_c = torch.ones(G, H, device=DEV), torch.ones(C, H, device=DEV)
+    zc, zg = f(ones_g, ones_c), fg(ones_g, ones_c)
+    del ones_g, ones_c
+    a64 = alpha.double()
+    row_c = torch.repeat_interleave(torch.arange(C, device=DEV), (g.cg.rowptr[1:] - g.cg.rowptr[:-1]).long())
+    want_c = torch.zeros(C, dtype=torch.float64, device=DEV).index_add_(0, row_c, g.cg.val.double() * a64[g.cg.col.long()])
+    want_c = (want_c + a64[G + 1]) * g.cg.inv_deg.double()
+    assert (zc.double() - want_c[:, None]).abs().max().item() < 1e-4
+    del row_c, want_c, zc
+    row_g = torch.repeat_interleave(torch.arange(G, device=DEV), (g.gc.rowptr[1:] - g.gc.rowptr[:-1]).long())
+    want_g = torch.zeros(G, dtype=torch.float64, device=DEV).index_add_(0, row_g, g.gc.val.double())
+    want_g = (a64[:G] * want_g + a64[G]) * g.gc.inv_deg.double()
+    assert (zg.double() - want_g[:, None]).abs().max().item() < 2e-4
+    del row_g, want_g, zg, z1, y1, hg1, hc1
+    # the bench's cfg5 forward: fp16-STORED [G + C, 400] features widened inside the projection kernel's loader (fp16-rounded
+    # inputs, fp32 multiply-accumulate, SURVEY 8d) == the same model on the fp32 copy of those rounded features
+    torch.manual_seed(5)
+    m = sda.GNN(cfg.dense_dim, H, cfg.n_classes, 2, G, activation=F.relu).to(DEV).eval()
+    with torch.no_grad():
+        m.alpha.uniform_(0.5, 1.5)
+        feats16 = S.synth_features(G + C, cfg.dense_dim, device=DEV, dtype=torch.float16)
+        out16 = m(g, feats16)
+        out32 = m(g, feats16.float())
+    assert out16.shape == (C, cfg.n_classes) and torch.isfinite(out16).all()
+    assert (out16 - out32).abs().max().item() < 1e-4
