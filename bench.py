@@ -230,8 +230,14 @@ def main():
         pass
 
     import scdeepsort_amd as sda
-    from scdeepsort_amd import synthetic as S
+    from scdeepsort_amd import synthetic as S, tuning
     from scdeepsort_amd.sharded import ShardedWgnn
+
+    # per-shape pick among the libraries' own GEMM kernels for the dense projections (selection only, tracked file;
+    # ignored on a different library stack - see scdeepsort_amd/tuning.py)
+    gemm_selection = "library heuristics"
+    if os.environ.get("WGNN_BENCH_TUNED_GEMMS", "1") == "1" and tuning.use_tuned_gemms():
+        gemm_selection = f"TunableOp picks from scdeepsort_amd/{tuning.TUNED_FILE.name} (selection only, no tuning at run time)"
 
     cfg = S.CONFIGS[args.config]
     G = cfg.genes
@@ -420,7 +426,7 @@ def main():
                            "cells_total": total_cells, "cells_this_rank": C,
                            "nnz_per_gpu": per_gpu[0]["nnz"] if per_gpu else roofline["passes"][0]["nnz"],
                            "parallelism": f"cell-shard x{world}", "setup_s": round(t_setup, 1), "communicator": comm,
-                           "step_launch": launch_desc, "eager_ms_per_step": eager_ms, "launch_calibration_ms": launch_calibration,
+                           "gemm_selection": gemm_selection, "step_launch": launch_desc, "eager_ms_per_step": eager_ms, "launch_calibration_ms": launch_calibration,
                            "sharded_vs_unsharded": self_check},
                 "roofline": roofline, "cpu_baseline": cpu, "sustained": sustained, "weak_scaling": weak}
         print(json.dumps(line))

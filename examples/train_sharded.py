@@ -39,7 +39,8 @@ def main():
     dev = torch.device("cuda", local)
 
     import scdeepsort_amd as sda
-    from scdeepsort_amd import synthetic as S
+    from scdeepsort_amd import synthetic as S, tuning
+    tuning.use_tuned_gemms()                                          # tracked per-shape picks among the library GEMM kernels
     from scdeepsort_amd.dist import shard_range
     from scdeepsort_amd.sharded import ShardedWgnn
 

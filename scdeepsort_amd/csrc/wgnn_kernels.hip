@@ -36,6 +36,7 @@ __global__ void __launch_bounds__(kBlock) agg_main(const KArgs a) {
     if (item >= a.n_items) return;                // whole wave exits together
     const int4 it = a.items[item];
     const int slot = it.x, begin = it.y, end = it.z, pslot = it.w;
+    if (slot < 0) return;                         // an unused item of a static-shape (device-built) plan: wave-uniform exit
     const int sub = lane / LPR, l = lane % LPR;
     const TIn* __restrict__ src = reinterpret_cast<const TIn*>(a.src);
 
@@ -124,6 +125,7 @@ __global__ void __launch_bounds__(kBlock) agg_finalize(const KArgs a) {
     const long idx = (long)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
     if (idx >= a.n_long) return;
     const int4 lr = a.long_rows[idx];
+    if (lr.x < 0) return;                         // unused long-row record of a static-shape plan
     const int sub = lane / LPR, l = lane % LPR;
     float4 acc[NV];
 #pragma unroll

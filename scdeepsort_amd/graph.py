@@ -108,14 +108,48 @@ def build_plan(rowptr_host: np.ndarray, chunk: Optional[int] = None, row_ids_hos
     return Plan(torch.from_numpy(items).to(device), torch.from_numpy(longs).to(device), int(npart.value), chunk)
 
 
-def device_plan(rowptr32: torch.Tensor, n_rows: int, max_row_nnz: int, chunk: int) -> Plan:
-    """Row-chunk plan built ON THE DEVICE with static shapes (no device->host copy): every row gets the same number
-    S = ceil(max_row_nnz / chunk) of items cut at multiples of ``chunk`` (later items of short rows are empty); S > 1
-    rows fold their S partial sums in ``agg_finalize``.  ``max_row_nnz`` is a host-known BOUND on the row length."""
+def device_plan(rowptr32: torch.Tensor, n_rows: int, max_row_nnz: int, chunk: int, nnz_bound: Optional[int] = None) -> Plan:
+    """Row-chunk plan built ON THE DEVICE with static shapes (no device->host copy).  ``max_row_nnz`` is a host-known BOUND
+    on the row length, S = min(8, ceil(max_row_nnz / chunk)) the number of parts a long row is cut into (their partial
+    sums are folded by ``agg_finalize``).
+
+    Without ``nnz_bound`` EVERY row gets S items cut at multiples of the chunk length (later items of short rows are
+    empty) and S partial rows.  With ``nnz_bound`` (a host-known bound on the number of entries) only rows LONGER than the
+    chunk are cut: there are fewer than nnz_bound / chunk of them, so a static number H of hub slots suffices - every row
+    keeps one item, hubs get S - 1 more (unused hub slots are items with row -1, which the kernels skip), and the partial
+    buffer holds H * S rows instead of n_rows * S (a [G * 8, D] buffer written and re-read per backward of a
+    sampled block where only the few hub genes need splitting)."""
     dev = rowptr32.device
     chunk = max(1, int(chunk), -(-int(max_row_nnz) // 8))     # at most 8 items per row, whatever the bound
     S = max(1, -(-int(max_row_nnz) // chunk))
     beg, ln = rowptr32[:-1], rowptr32[1:] - rowptr32[:-1]
+    if nnz_bound is not None and S > 1:
+        H = min(int(n_rows), int(nnz_bound) // chunk)         # rows longer than `chunk`: each holds > chunk of the <= nnz_bound entries
+        rows = torch.arange(n_rows, device=dev, dtype=torch.int32)
+        if H == 0:                                            # no row can exceed the chunk: one item per row
+            items = torch.stack([rows, beg, beg + ln, torch.full_like(rows, -1)], 1).contiguous()
+            return Plan(items, torch.empty((0, 4), dtype=torch.int32, device=dev), 0, chunk)
+        is_long = ln > chunk
+        rank = (torch.cumsum(is_long.to(torch.int32), 0) - 1).to(torch.int32)
+        cl = (ln + (S - 1)) // S                              # part length of a long row (S near-equal parts)
+        base = torch.stack([rows, beg, beg + torch.where(is_long, torch.minimum(cl, ln), ln),
+                            torch.where(is_long, rank * S, torch.full_like(rows, -1))], 1)
+        hub = torch.nonzero_static(is_long, size=H, fill_value=-1).squeeze(1)          # ascending row ids, -1 = unused slot
+        hv = hub >= 0
+        hr = hub.clamp(min=0)
+        h_beg, h_ln, h_cl = beg[hr], ln[hr], cl[hr]
+        j = torch.arange(1, S, device=dev, dtype=torch.int32).unsqueeze(0)             # parts 1 .. S-1
+        lo = h_beg.unsqueeze(1) + torch.minimum(j * h_cl.unsqueeze(1), h_ln.unsqueeze(1))
+        hi = h_beg.unsqueeze(1) + torch.minimum((j + 1) * h_cl.unsqueeze(1), h_ln.unsqueeze(1))
+        hslot = torch.arange(H, device=dev, dtype=torch.int32).unsqueeze(1)
+        row_e = torch.where(hv, hub.to(torch.int32), torch.full_like(hub, -1).to(torch.int32)).unsqueeze(1).expand(H, S - 1)
+        extra = torch.stack([row_e, lo.to(torch.int32), hi.to(torch.int32), (hslot * S + j).expand(H, S - 1)], 2).reshape(H * (S - 1), 4)
+        extra = torch.where(hv.repeat_interleave(S - 1).unsqueeze(1), extra,
+                            torch.tensor([-1, 0, 0, -1], dtype=torch.int32, device=dev).expand_as(extra))
+        items = torch.cat([base.to(torch.int32), extra.to(torch.int32)]).contiguous()
+        long_rows = torch.stack([row_e[:, 0], hslot[:, 0] * S, torch.full((H,), S, dtype=torch.int32, device=dev),
+                                 torch.zeros(H, dtype=torch.int32, device=dev)], 1).contiguous()
+        return Plan(items, long_rows, H * S, chunk)
     s = torch.arange(S, device=dev, dtype=torch.int32).unsqueeze(0)
     lo = beg.unsqueeze(1) + torch.minimum(s * chunk, ln.unsqueeze(1))
     hi = beg.unsqueeze(1) + torch.minimum((s + 1) * chunk, ln.unsqueeze(1))
@@ -171,7 +205,7 @@ class AggCsr:
             # a source is drawn by at most every row once; a hub source (up to n entries) is cut into <= 8 items of >= 2048
             # entries whose partial sums agg_finalize folds - one wave per source would serialise the hub genes
             self._t = AggCsr(t_rowptr32, owner[perm].to(torch.int32).contiguous(), t_val, torch.empty(0, device=dev),
-                             self.n_cols, n, device_plan(t_rowptr32, self.n_cols, max(1, n), TRANSPOSE_CHUNK), None)
+                             self.n_cols, n, device_plan(t_rowptr32, self.n_cols, max(1, n), TRANSPOSE_CHUNK, nnz_bound=n * kk), None)
             self._t._max_row_nnz = max(1, n)
         if self._t is None:
             dev = self.device
@@ -185,7 +219,8 @@ class AggCsr:
             t_val = self.val[order].contiguous()
             t_rowptr32 = t_rowptr.to(torch.int32)
             if self.rowptr_host is None:             # device-built block: a source feeds at most every row once
-                plan, host = device_plan(t_rowptr32, self.n_cols, max(1, self.n_rows), TRANSPOSE_CHUNK), None   # hub sources: <= 8 items
+                plan, host = device_plan(t_rowptr32, self.n_cols, max(1, self.n_rows), TRANSPOSE_CHUNK,
+                                         nnz_bound=self.nnz), None                  # only hub sources are cut (<= 8 items each)
             else:
                 host = t_rowptr32.cpu().numpy()
                 plan = build_plan(host, self.plan.chunk, device=dev)

@@ -254,3 +254,45 @@ def test_tile_plan_with_loader_waves_covers_every_edge_once():
             assert got == want, (rt, cs, L)
     crowded = GR.build_tile_plan(_cpu_agg_csr(X), 12, 1, block_rows=32, n_loaders=2)      # 250 rows per tile > 14 x 16
     assert crowded.n_loaders == 0
+
+
+def test_device_built_plan_cuts_only_hub_rows():
+    """the static-shape plan of a device-built (transposed / sampled) block gives every row ONE item and cuts only
+    the rows longer than the chunk, into <= 8 parts on a fixed number of hub slots (unused slots = items with row -1, which
+    the kernels skip) - not S items and S partial rows for every row.  Pure index arithmetic: checked on the CPU."""
+    from scdeepsort_amd.graph import device_plan
+    torch.manual_seed(0)
+    for trial in range(24):
+        n = int(torch.randint(1, 60, (1,)))
+        ln = torch.randint(0, 50, (n,), dtype=torch.int32)
+        if trial % 3 == 0:
+            ln[torch.randint(0, n, (1,))] = 5000 + trial            # a hub row
+        if trial % 5 == 0:
+            ln[:] = 3                                               # no row reaches the chunk
+        rp = torch.zeros(n + 1, dtype=torch.int32)
+        rp[1:] = torch.cumsum(ln, 0)
+        bound = int(ln.max()) + (0 if trial % 2 else 100)           # a BOUND on the row length, not necessarily tight
+        p = device_plan(rp, n, max(1, bound), 16, nnz_bound=int(rp[-1]) + (7 if trial % 2 else 0))
+        cover = torch.zeros(int(rp[-1]) + 1, dtype=torch.int32)
+        partial_slots = set()
+        for slot, b, e, ps in p.items.tolist():
+            if slot < 0:
+                continue
+            assert rp[slot] <= b <= e <= rp[slot + 1]
+            cover[b:e] += 1
+            if ps >= 0:
+                assert ps not in partial_slots and ps < p.n_partials
+                partial_slots.add(ps)
+        assert (cover[:-1] == 1).all()                              # every entry exactly once
+        longs = {i for i in range(n) if ln[i] > p.chunk}
+        assert {r[0] for r in p.long_rows.tolist() if r[0] >= 0} == longs
+        for slot, first, cnt, _ in p.long_rows.tolist():
+            if slot >= 0:
+                assert cnt <= 8 and all((first + k) in partial_slots for k in range(cnt))
+        direct = sorted(it[0] for it in p.items.tolist() if it[0] >= 0 and it[3] < 0)
+        assert direct == [i for i in range(n) if ln[i] <= p.chunk]   # short rows: one item, written directly
+        assert p.n_partials <= 8 * max(1, (int(rp[-1]) + 7) // p.chunk)
+    # the every-row form (no entry bound) is unchanged
+    rp = torch.tensor([0, 5, 5, 40], dtype=torch.int32)
+    q = device_plan(rp, 3, 40, 16)
+    assert q.items.shape[0] == 3 * 3 and q.n_partials == 9
