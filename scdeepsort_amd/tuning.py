@@ -48,6 +48,11 @@ def tune_gemms(workload: Callable[[], None], path: Optional[Path] = None, max_ms
         T.read_file(str(path))                       # keep earlier picks, add new shapes
     workload()
     torch.cuda.synchronize()
-    T.write_file(str(path))
     T.tuning_enable(False)
+    # the result file in TunableOp's own format (this torch has no write_file(); the C++ side only writes at exit)
+    with open(path, "w") as f:
+        for name, value in T.get_validators():
+            f.write(f"Validator,{name},{value}\n")
+        for op, params, solution, t in T.get_results():
+            f.write(f"{op},{params},{solution},{t}\n")
     return path
