@@ -409,6 +409,33 @@ def main():
                     "unit": "cells/s"}
             engine = w_engine
 
+    # ---- secondary (never `value`): BASELINE cfg4's training step on the same resident graph at N = 1 - forward (dropout 0.1) +
+    # CrossEntropyLoss(sum) + backward through K2t / the fused glue + Adam (reference train.py:80-87)
+    train_step = None
+    if world == 1 and not args.no_secondary and not cfg.total_cells and os.environ.get("WGNN_BENCH_TRAIN_STEP", "1") == "1":
+        torch.manual_seed(4321)
+        tm = sda.GNN(cfg.dense_dim, cfg.hidden, cfg.n_classes, cfg.n_layers, G, activation=F.relu, dropout=0.1).to(dev)
+        topt = torch.optim.Adam(tm.parameters(), lr=1e-3, weight_decay=5e-4, fused=True)
+        ty = (torch.arange(C, device=dev) * 2654435761 % cfg.n_classes).long()
+        tf = (feats_g.float(), feats_c.float())
+
+        def tstep():
+            loss = sda.cross_entropy_sum(tm(engine.graph, tf), ty)
+            topt.zero_grad(set_to_none=True); loss.backward(); topt.step()
+            return loss
+        for _ in range(3):
+            tl = tstep()
+        torch.cuda.synchronize()
+        n_tr = 10
+        t0 = time.perf_counter()
+        for _ in range(n_tr):
+            tl = tstep()
+        torch.cuda.synchronize()
+        train_step = {"ms_per_step": round((time.perf_counter() - t0) / n_tr * 1e3, 4), "steps": n_tr, "loss": round(float(tl), 2),
+                      "what": f"full-batch {cfg.name} training step at N = 1: forward (dropout 0.1) + CrossEntropyLoss(sum) + backward "
+                              "(K2t on pre-scaled rows, wgnn_agg_bwd_prepare, matrix-core weight gradients) + fused Adam"}
+        del tm, topt, tf
+
     # ---- CPU baseline: the restatement (C/OpenMP aggregation + torch Linear) on this host, rank 0, N = 1 only
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -428,7 +455,7 @@ def main():
                            "parallelism": f"cell-shard x{world}", "setup_s": round(t_setup, 1), "communicator": comm,
                            "gemm_selection": gemm_selection, "step_launch": launch_desc, "eager_ms_per_step": eager_ms, "launch_calibration_ms": launch_calibration,
                            "sharded_vs_unsharded": self_check},
-                "roofline": roofline, "cpu_baseline": cpu, "sustained": sustained, "weak_scaling": weak}
+                "roofline": roofline, "cpu_baseline": cpu, "sustained": sustained, "weak_scaling": weak, "train_step": train_step}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

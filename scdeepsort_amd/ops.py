@@ -618,7 +618,14 @@ def use_wgnn_linear(x: torch.Tensor, weight: torch.Tensor, dual: bool = False) -
         return WGNN_LINEAR_DUAL
     if WGNN_LINEAR == "always":
         return True
-    return x.dtype == torch.float16 or (x.shape[0] >= WGNN_LINEAR_MIN_ROWS and x.shape[1] >= WGNN_LINEAR_MIN_K)
+    if x.dtype == torch.float16:
+        return True                            # fp16-stored rows: widened in the kernel's loader, never materialised in fp32
+    from . import tuning
+    if tuning.active():
+        # with the tracked per-shape picks loaded the LIBRARY wins the one fp32 shape this kernel used to take: 155 us (tuned
+        # rocBLAS pick) vs 207 us here vs 232 us (the libraries' own heuristic) on 100k x 400 x 256 (round 4, scratch/tune_gemms.py)
+        return False
+    return x.shape[0] >= WGNN_LINEAR_MIN_ROWS and x.shape[1] >= WGNN_LINEAR_MIN_K
 
 
 def linear_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, relu: bool = False,

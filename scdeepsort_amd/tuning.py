@@ -17,6 +17,12 @@ from typing import Callable, Optional
 import torch
 
 TUNED_FILE = Path(__file__).resolve().parent / "tuned_gemms_gfx950.csv"
+_ACTIVE = False
+
+
+def active() -> bool:
+    """True once ``use_tuned_gemms`` has loaded a result file: the library GEMMs then run their tuned picks."""
+    return _ACTIVE
 
 
 def use_tuned_gemms(path: Optional[Path] = None) -> bool:
@@ -28,11 +34,14 @@ def use_tuned_gemms(path: Optional[Path] = None) -> bool:
     T.enable(True)
     T.tuning_enable(False)
     T.record_untuned_enable(False)
+    global _ACTIVE
     try:
-        return bool(T.read_file(str(path)))
+        _ACTIVE = bool(T.read_file(str(path)))
     except Exception:
+        _ACTIVE = False
+    if not _ACTIVE:
         T.enable(False)
-        return False
+    return _ACTIVE
 
 
 def tune_gemms(workload: Callable[[], None], path: Optional[Path] = None, max_ms_per_shape: int = 3000, iters: int = 50) -> Path:

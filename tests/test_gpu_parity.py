@@ -1988,3 +1988,40 @@ def test_full_size_properties_cfg5():
         out32 = m(g, feats16.float())
     assert out16.shape == (C, cfg.n_classes) and torch.isfinite(out16).all()
     assert (out16 - out32).abs().max().item() < 1e-4
+
+
+def test_tuned_gemm_picks_change_speed_not_results():
+    """`tuning.use_tuned_gemms()` (PyTorch TunableOp, selection only) routes the dense projections to the library kernels
+    recorded per shape in the tracked file: same logits to rounding, and the fp32 projections leave wgnn_linear_fwd for
+    the library (which wins once tuned); fp16-stored features keep the widening loader."""
+    import subprocess, sys as _sys, json as _json
+    from pathlib import Path
+    code = r'''
+import sys, json, torch, torch.nn.functional as F
+sys.path.insert(0, %r)
+import scdeepsort_amd as sda
+from scdeepsort_amd import synthetic as S, tuning, ops
+dev = "cuda:0"
+rp, col, val = S.synth_expression(60000, 3000, 0.03, device=dev)
+g = sda.CellGeneGraph.from_device_csr(rp, col, val, 3000)
+torch.manual_seed(0)
+m = sda.GNN(400, 256, 16, 2, 3000, activation=F.relu).to(dev).eval()
+f = S.synth_features(63000, 400, device=dev)
+x = f[3000:]
+with torch.no_grad():
+    before = m(g, f)
+    routed_before = ops.use_wgnn_linear(x, m.layers[0].fc_neigh.weight)
+    ok = tuning.use_tuned_gemms()
+    after = m(g, f)
+    routed_after = ops.use_wgnn_linear(x, m.layers[0].fc_neigh.weight)
+    routed_half = ops.use_wgnn_linear(x.half(), m.layers[0].fc_neigh.weight)
+print(json.dumps({"loaded": ok, "active": tuning.active(), "diff": float((before - after).abs().max()),
+                  "routed": [routed_before, routed_after, routed_half]}))
+''' % str(Path(sda.__file__).resolve().parent.parent)
+    r = subprocess.run([_sys.executable, "-c", code], capture_output=True, text=True, timeout=600)     # own process: TunableOp is global state
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = _json.loads(r.stdout.strip().splitlines()[-1])
+    assert rec["diff"] < 1e-4
+    assert rec["routed"][0] is True and rec["routed"][2] is True
+    if rec["loaded"]:                                            # (a different library stack ignores the file: nothing changes)
+        assert rec["active"] and rec["routed"][1] is False

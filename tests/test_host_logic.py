@@ -296,3 +296,17 @@ def test_device_built_plan_cuts_only_hub_rows():
     rp = torch.tensor([0, 5, 5, 40], dtype=torch.int32)
     q = device_plan(rp, 3, 40, 16)
     assert q.items.shape[0] == 3 * 3 and q.n_partials == 9
+
+
+def test_tracked_gemm_picks_file_is_wellformed():
+    """scdeepsort_amd/tuned_gemms_gfx950.csv (PyTorch TunableOp result format): validator lines naming the library stack it was
+    tuned against, then one `op,shape,solution,time` line per GEMM shape of the BASELINE workloads."""
+    from scdeepsort_amd import tuning
+    lines = tuning.TUNED_FILE.read_text().strip().splitlines()
+    vals = {l.split(",")[1]: l.split(",", 2)[2] for l in lines if l.startswith("Validator,")}
+    assert {"PT_VERSION", "HIPBLASLT_VERSION", "ROCBLAS_VERSION", "GCN_ARCH_NAME"} <= set(vals) and "gfx950" in vals["GCN_ARCH_NAME"]
+    picks = [l.split(",") for l in lines if not l.startswith("Validator,")]
+    assert len(picks) >= 10 and all(len(p) == 4 and p[0].startswith("Gemm") and float(p[3]) > 0 for p in picks)
+    shapes = {p[1] for p in picks}
+    assert "tn_256_100000_400_ld_400_400_256" in shapes          # cfg3's largest projection: [1e5, 400] x [400, 256]
+    assert not tuning.active()                                   # nothing is switched on by importing the package
