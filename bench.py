@@ -196,7 +196,10 @@ def main():
                     help="strong (default): ONE cfg-sized job, its cells sharded over the ranks (BASELINE cfg3/cfg4/cfg5); "
                          "weak: every rank owns a cfg-sized shard")
     ap.add_argument("--graphed", choices=("auto", "on", "off"), default="auto",
-                    help="replay the forward as ONE hipGraph launch per step (auto: launch-bound configs, i.e. small graphs at N = 1)")
+                    help="replay the forward as ONE hipGraph launch per step (auto: launch-bound configs, i.e. small graphs at N = 1; "
+                         "at N > 1 only with `on`: the captured sharded forward is then timed against eager issue and the faster one runs)")
+    ap.add_argument("--hidden", type=int, default=None, help="override the config's hidden width (e.g. 200, the reference's default "
+                                                             "hidden_dim, train.py:137) - a side measurement, not BASELINE's line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the weak-scaling / sustained secondary measurements")
     args = ap.parse_args()
@@ -240,6 +243,9 @@ def main():
         gemm_selection = f"TunableOp picks from scdeepsort_amd/{tuning.TUNED_FILE.name} (selection only, no tuning at run time)"
 
     cfg = S.CONFIGS[args.config]
+    if args.hidden:
+        import dataclasses
+        cfg = dataclasses.replace(cfg, hidden=int(args.hidden), name=f"{cfg.name} with hidden {int(args.hidden)}")
     G = cfg.genes
     mode = args.scaling
     t_setup = time.time()
@@ -258,11 +264,13 @@ def main():
     # launch-bound configs (cfg2: ~25 launches of a few us each): the same forward captured once and replayed as one hipGraph
     # launch per step (scdeepsort_amd.graphed.GraphedForward); per-launch HIP events cannot be recorded inside a replay, so
     # the roofline's per-kernel durations come from a short eager pass of the same forward outside the timed region
-    # N > 1: a rank's shard of the strong-scaling job is launch-bound as well (12.5k cells per rank at N = 8: ~15 short launches
-    # and two collectives per forward) - the whole sharded forward INCLUDING the RCCL collectives replays as one hipGraph
-    # (graphed.GraphedShardedForward; with a host-side backend such as gloo: graph segments around eager collectives)
+    # (graphed.GraphedShardedForward replays the whole sharded forward INCLUDING the RCCL collectives as one hipGraph; with a
+    # host-side backend such as gloo: graph segments around eager collectives)
+    # N > 1: "auto" issues the sharded forward EAGERLY - measured faster than the captured graph on the 1-GPU lease (a rank's shard
+    # is GPU-bound: profiles/r04_shard_trace.json), and a capture that includes RCCL collectives across real peers cannot be
+    # exercised on that lease; `--graphed on` captures it (GraphedShardedForward), times both and runs the faster one.
     graphed = (world == 1 and (args.graphed == "on" or (args.graphed == "auto" and cfg.cells * cfg.genes <= 100_000_000))) \
-        or (world > 1 and args.graphed != "off")
+        or (world > 1 and args.graphed == "on")
     step_fn, launch_desc, launch_calibration = None, "eager", None
     if graphed and world == 1:
         from scdeepsort_amd.graphed import GraphedForward
@@ -274,7 +282,7 @@ def main():
         step_fn = lambda: gf()
         launch_desc = ("hipGraph replay (1 launch per step, RCCL collectives captured)" if gf.mode == "whole" else
                        f"hipGraph replay in {gf.n_graphs} segments around {gf.n_eager_collectives} host-side collectives ({backend})")
-        if args.graphed == "auto":
+        if True:
             # Measured on the 1-GPU lease (profiles/r04_shard_trace.json): one rank's shard at N = 4 / 8 is GPU-bound, not
             # launch-bound - its ~15 kernels add up to the forward's wall time, the host runs ahead - and a graph replay costs
             # its fixed launch overhead on top (0.596 eager vs 0.637 ms replayed at 12.5k cells).  So "auto" times a few steps
@@ -336,8 +344,10 @@ def main():
         try:
             rec = json.loads(tf.read_text())
             ent = rec.get(f"{args.config}:{dom['rows']}x{dom['src_rows']}")
-            if isinstance(ent, dict) and ent.get("kernel") == dom["kernel"]:
-                traffic, traffic_src = ent["hbm_bytes_per_launch"], f"profiles/hbm_traffic.json ({rec.get('_captured', '?')})"
+            if isinstance(ent, dict) and ent.get("kernel") == dom["kernel"] and int(ent.get("D", 256)) == dom["D"]:
+                traffic = ent["hbm_bytes_per_launch"]
+                traffic_src = ("TRACKED capture, not a counter of this run (PMC needs rocprofv3 around the whole process): "
+                               f"profiles/hbm_traffic.json ({rec.get('_captured', '?')})")
         except Exception:
             traffic = None
     # measured device copy bandwidth (read + write of a 1 GiB fp32 buffer), outside the timed region: the achievable HBM rate

@@ -205,12 +205,12 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     debug mode.  The line must say n_gpus = 2 and carry one roofline record per rank."""
     env = dict(os.environ, WGNN_BENCH_SHARE_GPU="1", WGNN_BENCH_CONFIG="cfg2")
     env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
-    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+    r = subprocess.run([sys.executable, str(ROOT / "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--graphed", "on"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["config"]["communicator"]["ranks"] == 2
-    # the sharded forward was captured (graph segments around the gloo collectives here) and timed against eager issue;
+    # `--graphed on`: the sharded forward was captured (graph segments around the gloo collectives here) and timed against eager issue;
     # the line says which one the timed steps used and carries both calibration times
     assert set(line["config"]["launch_calibration_ms"]) == {"graphed", "eager"}
     assert line["config"]["step_launch"].startswith(("hipGraph replay", "eager (measured faster"))
