@@ -5,6 +5,10 @@ sys.path.insert(0, '/root/repo')
 import scdeepsort_amd as sda
 from scdeepsort_amd import synthetic as S, dist as D
 from scdeepsort_amd.sharded import ShardedWgnn
+from scdeepsort_amd import tuning
+TUNED = os.environ.get('TUNED', '0') == '1' and tuning.use_tuned_gemms()
+if os.environ.get('LT', '0') == '1':
+    torch.backends.cuda.preferred_blas_library("hipblaslt")
 N = int(os.environ.get('N', '8')); steps = int(os.environ.get('STEPS', '50'))
 dev = torch.device('cuda:0')
 cfg = S.CONFIGS['cfg3']; G = cfg.genes
@@ -29,7 +33,7 @@ def timeit(f, n):
     e0.record()
     for _ in range(n): f()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / n
-res = {"N": N, "cells": hi - lo}
+res = {"N": N, "cells": hi - lo, "tuned": bool(TUNED), "hipblaslt_preferred": os.environ.get("LT", "0") == "1"}
 for fold in (False, True):
     model.fold_alpha = fold
     res[f"eager_ms_fold{int(fold)}"] = round(timeit(step, steps), 4)
