@@ -169,8 +169,9 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
             if compact:
                 m_c = m_c[seeds_local.long()]
             h_g, h_c = h_g.to(m_g.dtype) * m_g, h_c.to(m_c.dtype) * m_c
-        if (last and ops.cells_mean_linear is not None and W.shape[0] == W.shape[1] and h_g.dtype == W.dtype
-                and not torch.is_grad_enabled()):
+        if last and ops.cells_mean_linear is not None and W.shape[0] == W.shape[1] and h_g.dtype == W.dtype:
+            # the last layer in the reference's literal order (gnn.py:65-66), in training as well (round 4; every step of it is
+            # differentiable): no replicated [G, H] x [H, H] projection of the gene rows, forward or backward
             kw = {"prescaled": True} if folded else {}
             h_c = (ops.cells_mean_linear(h_g, h_c, W, b, relu, **kw) if rows is None
                    else ops.cells_mean_linear(h_g, h_c, W, b, relu, rows, compact, **kw))

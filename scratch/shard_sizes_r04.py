@@ -31,12 +31,14 @@ for N in (1, 2, 4, 8):
             return eng.forward(feats_g, fc, gather_logits=False)
     for _ in range(3): step()
     torch.cuda.synchronize()
-    ops.PROFILE = []
+    n = 50
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    n = 20
-    for _ in range(n): step()
+    for _ in range(n): step()                      # the forward time: no per-launch events in the stream
     e1.record(); torch.cuda.synchronize()
+    ops.PROFILE = []
+    for _ in range(n): step()                      # a second pass with HIP events around every aggregation launch (per-pass table)
+    torch.cuda.synchronize()
     prof, ops.PROFILE = ops.PROFILE, None
     per = {}
     for tag, a, b_ in prof:
