@@ -89,8 +89,10 @@ class GraphedTrainStep:
 
 
 class GraphedShardedForward:
-    """hipGraph replay of the SHARDED no-grad forward (``ShardedWgnn.forward`` at world > 1): at 12.5k cells per rank
-    (cfg3 over 8 GPUs) the forward is ~15 short launches and two collectives, i.e. launch-bound when issued eagerly.
+    """hipGraph replay of the SHARDED no-grad forward (``ShardedWgnn.forward`` at world > 1): ~15 launches and two collectives.
+    Measured on one MI355X (round 4, ``profiles/r04_shard_trace.json``): a rank's shard of the cfg3 job is GPU-bound even at
+    12.5k cells (N = 8), so the replay is NOT faster than eager issue there (0.637 vs 0.596 ms) - this class exists for
+    smaller / launch-bound shards and for callers that want one launch per forward; ``bench.py`` uses it with ``--graphed on``.
 
     * ``nccl`` (RCCL): the collectives are captured WITH the kernels - the async [G, H] all-reduce on the communicator's
       stream (forked from / joined to the capture stream by events, so its overlap with the cells<-genes pass is part of the

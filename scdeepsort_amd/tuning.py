@@ -27,20 +27,21 @@ def active() -> bool:
 
 def use_tuned_gemms(path: Optional[Path] = None) -> bool:
     """Select the tracked per-shape GEMM picks (TunableOp on, tuning off).  Returns True when a result file was loaded."""
-    import torch.cuda.tunable as T
+    global _ACTIVE
     path = Path(path) if path is not None else TUNED_FILE
     if not torch.cuda.is_available() or not path.exists():
         return False
-    T.enable(True)
-    T.tuning_enable(False)
-    T.record_untuned_enable(False)
-    global _ACTIVE
-    try:
+    try:                                             # any missing piece of the TunableOp API = library heuristics, nothing else
+        import torch.cuda.tunable as T
+        T.enable(True)
+        T.tuning_enable(False)
+        if hasattr(T, "record_untuned_enable"):
+            T.record_untuned_enable(False)
         _ACTIVE = bool(T.read_file(str(path)))
+        if not _ACTIVE:
+            T.enable(False)
     except Exception:
         _ACTIVE = False
-    if not _ACTIVE:
-        T.enable(False)
     return _ACTIVE
 
 
