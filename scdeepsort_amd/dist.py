@@ -244,12 +244,15 @@ def all_reduce_grads(params) -> None:
 
 def sharded_train_step(params, weights_fn, feats_g, feats_c_local, labels_local, ops: LocalOps, n_layers: int,
                        optimizer, seeds_local: Optional[torch.Tensor] = None, dropout_masks=None, relu: bool = True,
-                       linear: Callable = torch.nn.functional.linear, loss_sum: Optional[Callable] = None) -> float:
+                       linear: Callable = torch.nn.functional.linear, loss_sum: Optional[Callable] = None,
+                       sync_loss: bool = True):
     """One full-batch data-parallel training step over cell shards (BASELINE cfg4).
 
     loss = CrossEntropyLoss(reduction='sum') over this rank's cells (train.py:36); because the loss is a SUM, adding
     the per-rank parameter gradients (all_reduce_grads) reproduces the single-process gradient exactly, and every rank
-    then applies the identical optimizer step.  Returns the global loss."""
+    then applies the identical optimizer step.  Returns the global loss: a Python float (``sync_loss``: one device->host read
+    per step, which also lets the host wait for the whole step before it enqueues the next one - ~0.9 ms of exposed launch
+    latency per cfg3 step) or, with ``sync_loss=False``, a 0-d device tensor the caller reads when it wants to."""
     logits = sharded_forward(weights_fn(), None, feats_g, feats_c_local, ops, n_layers, gather_logits=False,
                              dropout_masks=dropout_masks, relu=relu, linear=linear, seeds_local=seeds_local)
     loss = loss_sum(logits, labels_local) if loss_sum is not None else \
@@ -260,4 +263,4 @@ def sharded_train_step(params, weights_fn, feats_g, feats_c_local, labels_local,
     optimizer.step()
     total = loss.detach().clone()
     all_reduce_sum_(total)
-    return float(total)
+    return float(total) if sync_loss else total

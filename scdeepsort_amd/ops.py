@@ -706,6 +706,28 @@ class _LinearBigM(torch.autograd.Function):
         return dx, dw, db
 
 
+class _LinearReluBigM(torch.autograd.Function):
+    """``relu(x W^T + b)`` of the aggregate-first order in TRAINING (gnn.py:65-66 under train.py:84): bias and ReLU ride in the
+    library GEMM's epilogue as on the no-grad path; backward masks the upstream gradient and reduces the bias gradient in ONE
+    ``wgnn_agg_bwd_prepare`` launch (instead of a threshold pass + a column-sum pass over [rows, H]), the weight gradient runs
+    on ``wgnn_linear_wgrad``."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        out = torch._addmm_activation(bias, x, weight.t())
+        ctx.save_for_backward(x, weight, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, weight, out = ctx.saved_tensors
+        res = agg_bwd_prepare(gout, out, None, None, NO_ALPHA, 0, want_scaled=True, want_dbias=ctx.needs_input_grad[2])
+        g = res["g_scaled"]                                           # gout * (out > 0)
+        dx = g @ weight if ctx.needs_input_grad[0] else None
+        dw = linear_wgrad(g, x).to(weight.dtype) if ctx.needs_input_grad[1] else None
+        return dx, dw, res["dbias"]
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``F.linear`` for the model's projections; in training on many rows the weight gradient uses the matrix-core kernel;
     with nothing to differentiate, fp16-stored inputs and the shapes where it wins run through ``wgnn_linear_fwd_ex``."""
@@ -734,5 +756,10 @@ def linear_act(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
             return torch._addmm_activation(bias, x, weight.t())      # the plain composition below
         except (RuntimeError, TypeError):
             pass
+    if (FUSED_BWD_GLUE and relu and bias is not None and torch.is_grad_enabled() and weight.requires_grad and x.is_cuda
+            and x.dim() == 2 and x.shape[0] >= WGRAD_MIN_ROWS and x.dtype == weight.dtype == bias.dtype == torch.float32
+            and weight.shape[0] % 4 == 0 and weight.shape[1] % 4 == 0 and weight.shape[0] <= 1024
+            and hasattr(torch, "_addmm_activation")):
+        return _LinearReluBigM.apply(x, weight, bias)
     out = linear(x, weight, bias)
     return torch.relu(out) if relu else out

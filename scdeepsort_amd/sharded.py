@@ -172,15 +172,17 @@ class ShardedWgnn:
         return [(D.dropout_mask((feats_g.shape[0], w), p, self._gen_shared, dev),
                  D.dropout_mask((feats_c_local.shape[0], w), p, self._gen_local, dev)) for w in widths]
 
-    def train_step(self, feats_g, feats_c_local, labels_local, optimizer, seeds_local=None, dropout_masks=None) -> float:
+    def train_step(self, feats_g, feats_c_local, labels_local, optimizer, seeds_local=None, dropout_masks=None,
+                   sync_loss: bool = True):
         """Data-parallel full-batch step (cfg4): local CE-sum loss, SUM all-reduce of gradients, identical Adam step.
-        Dropout (train.py:26-32 passes ``dropout`` into GNN) is applied to every layer's input rows like gnn.py:60-64."""
+        Dropout (train.py:26-32 passes ``dropout`` into GNN) is applied to every layer's input rows like gnn.py:60-64.
+        Returns the global loss as a float, or (``sync_loss=False``) as a 0-d device tensor - no host synchronisation per step."""
         self.model.train()
         if dropout_masks is None:
             dropout_masks = self.dropout_masks(feats_g, feats_c_local)
         return D.sharded_train_step(list(self.model.parameters()), self._weights, feats_g, feats_c_local, labels_local,
                                     self._ops(), self.model.n_layers, optimizer, seeds_local, dropout_masks, self.relu, _linear,
-                                    cross_entropy_sum)
+                                    cross_entropy_sum, sync_loss)
 
     def forward(self, feats_g: torch.Tensor, feats_c_local: torch.Tensor, gather_logits: bool = True,
                 async_gather: bool = False) -> torch.Tensor:

@@ -2025,3 +2025,28 @@ print(json.dumps({"loaded": ok, "active": tuning.active(), "diff": float((before
     assert rec["routed"][0] is True and rec["routed"][2] is True
     if rec["loaded"]:                                            # (a different library stack ignores the file: nothing changes)
         assert rec["active"] and rec["routed"][1] is False
+
+
+@pytest.mark.parametrize("M,N,K", [(20000, 256, 256), (16500, 200, 52), (40000, 16, 256)])
+def test_linear_act_training_path_fused_relu_and_bias_gradient(M, N, K):
+    """ops.linear_act in TRAINING on many rows (the aggregate-first last layer, gnn.py:65-66 under train.py:84): bias + ReLU in the
+    GEMM epilogue, backward = one wgnn_agg_bwd_prepare launch (ReLU mask + bias gradient) + matrix-core weight gradient -
+    output and all three gradients against torch autograd in fp64."""
+    from scdeepsort_amd import ops
+    gen = torch.Generator(device=DEV).manual_seed(M + N)
+    x = torch.randn(M, K, generator=gen, device=DEV).requires_grad_(True)
+    W = (torch.randn(N, K, generator=gen, device=DEV) / K ** 0.5).requires_grad_(True)
+    b = torch.randn(N, generator=gen, device=DEV).requires_grad_(True)
+    up = torch.randn(M, N, generator=gen, device=DEV)
+    out = ops.linear_act(x, W, b, True)
+    assert out.grad_fn is not None and "LinearReluBigM" in type(out.grad_fn).__name__
+    (out * up).sum().backward()
+    x64, W64, b64 = (t.detach().double().requires_grad_(True) for t in (x, W, b))
+    ref = torch.relu(F.linear(x64, W64, b64))
+    (ref * up.double()).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), atol=2e-5)
+    # entries of `out` within rounding of 0 may take the other side of the ReLU mask: compare gradients where the mask is certain
+    sure = (ref.detach().abs() > 1e-5) | (ref.detach() == 0) & ((F.linear(x64, W64, b64)).detach() < -1e-5)
+    assert sure.float().mean().item() > 0.999
+    for got, want, scale in ((x.grad, x64.grad, 1.0), (W.grad, W64.grad, M ** 0.5), (b.grad, b64.grad, M ** 0.5)):
+        assert (got.double() - want).abs().max().item() < 5e-5 * scale + 1e-4 * want.abs().max().item()
