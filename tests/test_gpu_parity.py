@@ -2041,12 +2041,13 @@ def test_linear_act_training_path_fused_relu_and_bias_gradient(M, N, K):
     out = ops.linear_act(x, W, b, True)
     assert out.grad_fn is not None and "LinearReluBigM" in type(out.grad_fn).__name__
     (out * up).sum().backward()
-    x64, W64, b64 = (t.detach().double().requires_grad_(True) for t in (x, W, b))
-    ref = torch.relu(F.linear(x64, W64, b64))
-    (ref * up.double()).sum().backward()
-    np.testing.assert_allclose(out.detach().cpu().numpy(), ref.detach().cpu().numpy(), atol=2e-5)
-    # entries of `out` within rounding of 0 may take the other side of the ReLU mask: compare gradients where the mask is certain
-    sure = (ref.detach().abs() > 1e-5) | (ref.detach() == 0) & ((F.linear(x64, W64, b64)).detach() < -1e-5)
-    assert sure.float().mean().item() > 0.999
-    for got, want, scale in ((x.grad, x64.grad, 1.0), (W.grad, W64.grad, M ** 0.5), (b.grad, b64.grad, M ** 0.5)):
-        assert (got.double() - want).abs().max().item() < 5e-5 * scale + 1e-4 * want.abs().max().item()
+    x64, W64, b64 = (t.detach().double() for t in (x, W, b))
+    pre = F.linear(x64, W64, b64)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), torch.relu(pre).cpu().numpy(), atol=2e-5)
+    # pre-activations within rounding of 0 may fall on either side of the ReLU in fp32: the gradients are checked for the mask
+    # the forward actually produced (it differs from the fp64 mask on a handful of entries at most)
+    mask = (out.detach() > 0)
+    assert (mask != (pre > 0)).float().mean().item() < 1e-4
+    gm = up.double() * mask
+    for got, want in ((x.grad, gm @ W64), (W.grad, gm.t() @ x64), (b.grad, gm.sum(0))):
+        assert (got.double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
