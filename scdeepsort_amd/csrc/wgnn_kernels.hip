@@ -131,12 +131,26 @@ __global__ void __launch_bounds__(kBlock) agg_finalize(const KArgs a) {
 #pragma unroll
     for (int k = 0; k < NV; ++k) acc[k] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (sub == 0) {
-        for (int p = 0; p < lr.z; ++p) {
-            const float* pp = a.partials + (size_t)(lr.y + p) * a.D;
+        // groups of four partial rows: all four requested before any is added (the loop is a chain of L2 round trips
+        // otherwise - one wave per row, 3 .. 48 parts); rows past the end re-read the last one and are dropped by a select.
+        // The ADDITION order stays p = 0, 1, 2, ...
+        const float* base = a.partials + (size_t)lr.y * a.D;
+        const int n = lr.z;
+        for (int p = 0; p < n; p += 4) {
 #pragma unroll
             for (int k = 0; k < NV; ++k) {
                 const int c0 = (k * LPR + l) * 4;
-                if (c0 < a.D) { const float4 v = ld4(pp + c0); acc[k].x += v.x; acc[k].y += v.y; acc[k].z += v.z; acc[k].w += v.w; }
+                if (c0 < a.D) {
+                    float4 v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) v[i] = ld4(base + (size_t)min(p + i, n - 1) * a.D + c0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const bool on = p + i < n;                       // wave-uniform
+                        acc[k].x += on ? v[i].x : 0.f; acc[k].y += on ? v[i].y : 0.f;
+                        acc[k].z += on ? v[i].z : 0.f; acc[k].w += on ? v[i].w : 0.f;
+                    }
+                }
             }
         }
     }
