@@ -139,12 +139,20 @@ class GNN(nn.Module):
             p_g_scaled = None
             tiled_cells = (_ops.tiled_kernel_serves(g.cg, Hp) and not torch.is_grad_enabled()
                            and (cell_rows is None or cell_rows.shape[0] >= _ops.SEED_FULL_PASS_MIN_FRAC * g.cg.n_rows))
+            need_all_cells = (want_genes or not compact) and not h_c_compact
+            p_c_all = None
+            joint = self._adjacent_rows(h_g, h_c) if (need_all_cells and not torch.is_grad_enabled()) else None
             if tiled_cells and _ops.use_wgnn_linear(h_g, W, dual=True):
                 p_g, p_g_scaled = _ops.linear_fwd(h_g, W, row_scale=self.alpha.reshape(-1)[:G])
+            elif joint is not None and not _ops.use_wgnn_linear(h_c, W):
+                # gene and cell rows are one contiguous [G + C, D] table (features given as one tensor, preprocess_internal.py:202)
+                # and the graph is small: ONE projection GEMM instead of two latency-bound ones (cfg2: 17 vs 27 us)
+                p_all = _linear(joint, W)
+                p_g, p_c_all = p_all[:G], p_all[G:]
             else:
                 p_g = _linear(h_g, W)
-            need_all_cells = (want_genes or not compact) and not h_c_compact
-            p_c_all = _linear(h_c, W) if need_all_cells else None
+            if need_all_cells and p_c_all is None:
+                p_c_all = _linear(h_c, W)
             self_compact = compact
             if h_c_compact:
                 p_c_self = _linear(h_c, W)
@@ -171,6 +179,19 @@ class GNN(nn.Module):
             z_g = weighted_mean_aggregate(g.gc, self.alpha, DST_IS_GENE, G, h_c, h_g)
             out_g = finish(_linear_act(z_g, W, b, fuse_relu))
         return out_g, finish(out_c)
+
+    JOINT_PROJECTION_MAX_ROWS = 32768     # above this the two projections are bandwidth- / flop-bound and have their own tuned picks
+
+    def _adjacent_rows(self, h_g: torch.Tensor, h_c: torch.Tensor) -> Optional[torch.Tensor]:
+        """``[h_g; h_c]`` as ONE tensor without a copy when the two are consecutive row ranges of the same contiguous table
+        (``embed`` slices a single ``features`` tensor that way), for small graphs; else None."""
+        if (h_g.dim() != 2 or h_c.dim() != 2 or h_g.dtype != h_c.dtype or h_g.shape[1] != h_c.shape[1]
+                or h_g.shape[0] + h_c.shape[0] > self.JOINT_PROJECTION_MAX_ROWS
+                or not (h_g.is_contiguous() and h_c.is_contiguous())
+                or h_g.untyped_storage().data_ptr() != h_c.untyped_storage().data_ptr()
+                or h_c.storage_offset() != h_g.storage_offset() + h_g.numel()):
+            return None
+        return torch.as_strided(h_g, (h_g.shape[0] + h_c.shape[0], h_g.shape[1]), (h_g.shape[1], 1), h_g.storage_offset())
 
     def _fold_alpha_into_gene_rows(self, g: CellGeneGraph, layer: NodeUpdate, cell_rows) -> bool:
         """Whether the second-to-last layer may write its gene rows alpha-folded (see ``embed``): that layer runs

@@ -2051,3 +2051,39 @@ def test_linear_act_training_path_fused_relu_and_bias_gradient(M, N, K):
     gm = up.double() * mask
     for got, want in ((x.grad, gm @ W64), (W.grad, gm.t() @ x64), (b.grad, gm.sum(0))):
         assert (got.double() - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+
+
+def test_joint_projection_of_one_feature_table_matches_separate_projections():
+    """Small graphs: when `features` is ONE [G + C, D] tensor the layer-1 projections of gene and cell rows run as one GEMM over
+    the whole table (no copy: the two slices are adjacent rows of one storage); same logits as with (gene, cell) tensors
+    passed separately, and as the oracle.  Only without grad, only below GNN.JOINT_PROJECTION_MAX_ROWS."""
+    from scdeepsort_amd import ops
+    c = small_case(cells=300, genes=120, dim=40, hidden=24, n_classes=5, seed=9, test_cells=20)
+    sd = O.init_params(40, 24, 5, 2, 120, seed=4)
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
+    m = make_model(sd, 40, 24, 5, 2, 120)
+    f = dev(c["feats"])
+    calls = []
+    real = ops.linear
+    import scdeepsort_amd.gnn as GN
+    spy = lambda x, W, b=None: (calls.append(tuple(x.shape)), real(x, W, b))[1]
+    old = GN._linear
+    GN._linear = spy
+    try:
+        with torch.no_grad():
+            one = m(g, f)
+            n_one = list(calls); calls.clear()
+            two = m(g, (f[:120].clone(), f[120:].clone()))
+            n_two = list(calls); calls.clear()
+        out_grad = m(g, f)                                           # grad mode: separate projections (autograd through slices costs more)
+        n_grad = list(calls)
+    finally:
+        GN._linear = old
+    assert (420, 40) in n_one and (120, 40) not in n_one
+    assert (120, 40) in n_two and (300, 40) in n_two and (420, 40) not in n_two
+    assert (420, 40) not in n_grad
+    want = O.csr_forward(sd, O.build_csr_graph(c["expr"], c["support_mask"]), c["feats"], 2)
+    np.testing.assert_allclose(one.cpu().numpy(), want, atol=TOL)
+    assert (one - two).abs().max().item() < 2e-6 and (one - out_grad.detach()).abs().max().item() < 2e-6
+    m.JOINT_PROJECTION_MAX_ROWS = 100
+    assert m._adjacent_rows(f[:120], f[120:]) is None
