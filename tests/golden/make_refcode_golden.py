@@ -172,6 +172,17 @@ def make_case(name, gnn_mod, pre_mod, expr, support_mask, dim, hidden, n_classes
                batch=batch, labels=labels, loss=float(loss))
     for k, p in model.named_parameters():
         out["grad." + k] = p.grad.numpy().copy()
+    # round 4: the FULL-batch step (every cell a seed, in node order) - the shape of BASELINE cfg4's training step, which the
+    # product runs through its fused backward glue (wgnn_agg_bwd_prepare) and loss kernel; own label stream, drawn last so
+    # that everything above is unchanged
+    full_labels = np.random.default_rng(seed + 1).integers(0, n_classes, len(seeds))
+    nff = NodeFlowStandIn(src2, dst2, w2, node_id, feats, seeds, n_layers)
+    full_loss = torch.nn.CrossEntropyLoss(reduction='sum')(model(nff), torch.from_numpy(full_labels))   # REFERENCE CODE + autograd
+    model.zero_grad()
+    full_loss.backward()
+    out.update(full_labels=full_labels, full_loss=float(full_loss))
+    for k, p in model.named_parameters():
+        out["fullgrad." + k] = p.grad.numpy().copy()
     for k, v in model.state_dict().items():
         out["param." + k] = v.numpy()
     np.savez_compressed(HERE / f"{name}.npz", **out)

@@ -708,6 +708,51 @@ def test_hip_gradients_match_executed_reference_code(name):
         np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=TOL * max(1.0, float(np.abs(ref).max())), err_msg=k)
 
 
+@pytest.mark.parametrize("name", ["refcode_train", "refcode_predict", "refcode_1layer"])
+def test_fused_loss_kernel_matches_executed_reference_code(name):
+    """Round 4: the same fixtures (loss and gradients autograd produced through the reference's own `GNN.forward` +
+    `CrossEntropyLoss(reduction='sum')`, train.py:36,80-84) with the loss computed by `wgnn_ce_sum_fwd_bwd`
+    (`sda.cross_entropy_sum`) instead of the framework's log_softmax / nll_loss pair."""
+    z = np.load(GOLDEN / f"{name}.npz")
+    sd = {k[len("param."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param.")}
+    expr = sp.csr_matrix(z["expr"]); G = expr.shape[1]
+    g = sda.CellGeneGraph.from_expression(expr, z["support_mask"], device=DEV)
+    m = make_model(sd, int(z["dim"]), int(z["hidden"]), int(z["n_classes"]), int(z["n_layers"]), G).train()
+    logits = m(g, dev(z["feats"]), seeds=torch.from_numpy(z["batch"]).to(DEV))
+    loss = sda.cross_entropy_sum(logits, torch.from_numpy(z["labels"]).to(DEV))
+    loss.backward()
+    assert abs(float(loss) - float(z["loss"])) < 1e-4 * max(1.0, abs(float(z["loss"])))
+    for k, p in m.named_parameters():
+        ref = z["grad." + k]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=TOL * max(1.0, float(np.abs(ref).max())), err_msg=k)
+
+
+@pytest.mark.parametrize("name", ["refcode_train", "refcode_predict", "refcode_1layer"])
+@pytest.mark.parametrize("order", ["auto", "project_first"])
+def test_fused_full_batch_step_matches_executed_reference_code(name, order, monkeypatch):
+    """Round 4: the full-batch training step on the LDS-streamed route - K1t forward, `wgnn_ce_sum_fwd_bwd`, one
+    `wgnn_agg_bwd_prepare` launch per pass, K2t on pre-scaled rows - against the loss and gradients autograd produced through
+    the reference's own `GNN.forward` for every cell as a seed (tests/golden/make_refcode_golden.py, `fullgrad.*`)."""
+    from scdeepsort_amd import ops
+    z = np.load(GOLDEN / f"{name}.npz")
+    sd = {k[len("param."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param.")}
+    expr = sp.csr_matrix(z["expr"]); G = expr.shape[1]
+    g = sda.CellGeneGraph.from_expression(expr, z["support_mask"], device=DEV)
+    monkeypatch.setattr(ops, "TILED_MIN_WORK", 1)
+    calls = []
+    real = ops.agg_bwd_prepare
+    monkeypatch.setattr(ops, "agg_bwd_prepare", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    m = make_model(sd, int(z["dim"]), int(z["hidden"]), int(z["n_classes"]), int(z["n_layers"]), G, order).train()
+    logits = m(g, dev(z["feats"]))                                    # seeds=None: all cells in node order
+    loss = sda.cross_entropy_sum(logits, torch.from_numpy(z["full_labels"]).to(DEV))
+    loss.backward()
+    assert len(calls) == (3 if int(z["n_layers"]) == 2 else 1), calls          # every pass went through the fused glue
+    assert abs(float(loss) - float(z["full_loss"])) < 1e-4 * max(1.0, abs(float(z["full_loss"])))
+    for k, p in m.named_parameters():
+        ref = z["fullgrad." + k]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=TOL * max(1.0, float(np.abs(ref).max())), err_msg=k)
+
+
 def test_hipgraph_replay_matches_eager():
     """GraphedForward: the forward captured into a HIP graph replays to the same logits, also on new features."""
     from scdeepsort_amd.graphed import GraphedForward

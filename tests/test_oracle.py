@@ -212,6 +212,19 @@ def test_gradient_oracle_matches_executed_reference_code(name):
         np.testing.assert_allclose(gval.numpy(), z["grad." + k], atol=3e-6, rtol=1e-5, err_msg=k)
 
 
+@pytest.mark.parametrize("name", ["refcode_train", "refcode_predict", "refcode_1layer"])
+def test_full_batch_gradient_oracle_matches_executed_reference_code(name):
+    """Round 4: the FULL-batch step (every cell a seed: BASELINE cfg4's shape) through the reference's own GNN code + autograd,
+    against the oracle - the fixture the GPU test of the fused backward glue / loss kernel is pinned to."""
+    z, sd = _load_refcode(name)
+    rg = O.build_reference_graph(sp.csr_matrix(z["expr"]), z["support_mask"])
+    loss, grads, _ = O.loss_and_grads(sd, rg, torch.from_numpy(z["feats"]), z["seeds"], torch.from_numpy(z["full_labels"]),
+                                      int(z["n_layers"]))
+    assert abs(float(loss) - float(z["full_loss"])) < 1e-5 * max(1.0, abs(float(z["full_loss"])))
+    for k, gval in grads.items():
+        np.testing.assert_allclose(gval.numpy(), z["fullgrad." + k], atol=3e-6, rtol=1e-5, err_msg=k)
+
+
 def _kat_rational():
     import json
     kat = json.loads((GOLDEN / "kat_2layer_predict.json").read_text())
