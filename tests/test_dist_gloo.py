@@ -81,6 +81,36 @@ def _worker(rank, world, port, out_dir, cells=90):
         if res[1] is not None:
             res[1].wait()
         assert torch.equal(res[0], logits)
+        # ---- round 4: the capture hook sees exactly the data-path collectives (all-reduce of the gene partial sums, logits concat),
+        # runs them synchronously, and the result does not change (graphed.GraphedShardedForward cuts its hipGraph there)
+        seen = []
+        D.COLLECTIVE_HOOK = lambda fn: (seen.append(1), fn())[1]
+        try:
+            lh = D.sharded_forward(weights, None, feats[:G], feats[G + lo:G + hi], ops, 2, True, sizes)
+        finally:
+            D.COLLECTIVE_HOOK = None
+        assert len(seen) == 2 and torch.equal(lh, logits)
+        # ---- round 4: the last layer in the reference's literal order (aggregate, then Linear + ReLU: `cells_mean_linear`) with
+        # the gene rows handed over alpha-folded by `genes_finish(scale_out=True)` - inference; and the same order in training
+        flags = []
+        def cml(h_g, h_c, W, b, relu, rows=None, sc=False, prescaled=False):
+            flags.append(prescaled)
+            src = h_g if prescaled else alpha[:G, None] * h_g
+            z = ((Acg @ src) + alpha[G + 1] * h_c) * inv_c[:, None]
+            y = z @ W.t() + b
+            return torch.relu(y) if relu else y
+        def gfin(part, p_g, b, relu, scale_out=False):
+            y = torch.relu((alpha[:G, None] * part + alpha[G] * p_g) * inv_g[:, None].double() + b)
+            return alpha[:G, None] * y if scale_out else y
+        ops2 = D.LocalOps(ops.cells_layer, ops.genes_partial, gfin, cml, lambda width, n_seed: True)
+        with torch.no_grad():
+            l_fold = D.sharded_forward(weights, None, feats[:G], feats[G + lo:G + hi], ops2, 2, True, sizes)
+        assert flags == [True]
+        np.testing.assert_allclose(l_fold.numpy(), full, atol=1e-6)
+        flags.clear()
+        l_grad = D.sharded_forward(weights, None, feats[:G], feats[G + lo:G + hi], ops2, 2, True, sizes)      # grad mode: no fold
+        assert flags == [False]
+        np.testing.assert_allclose(l_grad.numpy(), full, atol=1e-6)
         # fp16-stored features (cfg5): widened on the way into the projection
         f16 = feats.half()
         l3 = D.sharded_forward(weights, None, f16[:G], f16[G + lo:G + hi], ops, 2, True, sizes)
@@ -122,6 +152,19 @@ def _worker(rank, world, port, out_dir, cells=90):
         assert abs(total - float(loss_ref)) < 1e-5 * max(1.0, abs(float(loss_ref)))
         for k, p_ in params.items():
             np.testing.assert_allclose(p_.grad.numpy(), grads_ref[k].numpy(), atol=1e-6, rtol=1e-4, err_msg=k)   # fp32-normalised graph weights in the oracle
+
+        # round 4: the same step with the LAST layer in the reference's literal order (`cells_mean_linear`, also in training):
+        # same loss, same all-reduced gradients
+        def tcml(h_g, h_c, W, b, relu, rows=None, sc=False, prescaled=False):
+            assert not prescaled                                        # folding is an inference-path fusion
+            y = (((Acg @ (al[:G, None] * h_g)) + al[G + 1] * h_c) * inv_c[:, None]) @ W.t() + b
+            return torch.relu(y) if relu else y
+        tops2 = D.LocalOps(tops.cells_layer, tops.genes_partial, tops.genes_finish, tcml, lambda width, n_seed: True)
+        total2 = D.sharded_train_step(list(params.values()), wfn, feats[:G], feats[G + lo:G + hi], labels[lo:hi], tops2, 2, opt,
+                                      sync_loss=False)
+        assert torch.is_tensor(total2) and abs(float(total2) - float(loss_ref)) < 1e-5 * max(1.0, abs(float(loss_ref)))
+        for k, p_ in params.items():
+            np.testing.assert_allclose(p_.grad.numpy(), grads_ref[k].numpy(), atol=1e-6, rtol=1e-4, err_msg=k + " (aggregate-first)")
 
         # SUM all-reduce of gradients == single-process gradient of the summed loss (train.py:36)
         p = torch.nn.Parameter(torch.ones(5, dtype=torch.float64))

@@ -310,3 +310,10 @@ def test_tracked_gemm_picks_file_is_wellformed():
     shapes = {p[1] for p in picks}
     assert "tn_256_100000_400_ld_400_400_256" in shapes          # cfg3's largest projection: [1e5, 400] x [400, 256]
     assert not tuning.active()                                   # nothing is switched on by importing the package
+
+
+def test_tuned_gemm_selection_is_a_no_op_without_a_gpu():
+    from scdeepsort_amd import tuning
+    if not torch.cuda.is_available():
+        assert tuning.use_tuned_gemms() is False and not tuning.active()
+    assert tuning.use_tuned_gemms("/nonexistent/file.csv") is False
