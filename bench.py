@@ -400,11 +400,11 @@ def main():
         roofline["job_forward_achieved_GBs"] = round(sum(p["forward_alg_bytes"] for p in per_gpu) / ms_per_step / 1e6, 1)
         roofline["job_forward_frac"] = round(roofline["job_forward_achieved_GBs"] / roofline["aggregate_peak_GBs"], 4)
 
-    # ---- secondary measurements (never `value`): a sustained run of the same step (>= ~1 s of GPU time, so that an
+    # ---- secondary measurements (never `value`): a sustained run of the same step (>= ~3 s of GPU time, so that an
     # outside sampler sees the device busy and the average is not 20 steps thin), and - N > 1 - the weak-scaling line
     sustained, weak = None, None
     if not args.no_secondary:
-        n_sus = max(args.steps, min(2000, int(1.2 / max(dt / args.steps, 1e-5))))
+        n_sus = max(args.steps, min(20000, int(3.0 / max(dt / args.steps, 1e-5))))     # >= 3 s of the same step back to back
         dt_s, _, _, _ = timed_steps(engine, feats_g, feats_c, n_sus, 0, world, dev, profile=False, step=step_fn)
         sustained = {"steps": n_sus, "ms_per_step": round(dt_s / n_sus * 1e3, 4), "value": round(total_cells / (dt_s / n_sus), 1),
                      "unit": "cells/s"}

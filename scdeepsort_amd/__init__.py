@@ -16,4 +16,4 @@ from .sampler import DeviceSampler
 __all__ = ["GNN", "NodeUpdate", "DeepSortClassifier", "DeepSortPredictor", "CellGeneGraph", "AggCsr", "Plan", "build_plan", "agg_fwd", "agg_bwd_src",
            "agg_bwd_alpha", "weighted_mean_aggregate", "linear_fwd", "DeviceSampler", "GraphedForward", "GraphedShardedForward", "GraphedTrainStep", "cross_entropy_sum",
            "WgnnError", "SRC_IS_GENE", "DST_IS_GENE", "NO_ALPHA"]
-__version__ = "0.1.0"
+__version__ = "0.4.0"
