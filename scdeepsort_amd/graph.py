@@ -144,8 +144,11 @@ def device_plan(rowptr32: torch.Tensor, n_rows: int, max_row_nnz: int, chunk: in
         hslot = torch.arange(H, device=dev, dtype=torch.int32).unsqueeze(1)
         row_e = torch.where(hv, hub.to(torch.int32), torch.full_like(hub, -1).to(torch.int32)).unsqueeze(1).expand(H, S - 1)
         extra = torch.stack([row_e, lo.to(torch.int32), hi.to(torch.int32), (hslot * S + j).expand(H, S - 1)], 2).reshape(H * (S - 1), 4)
-        extra = torch.where(hv.repeat_interleave(S - 1).unsqueeze(1), extra,
-                            torch.tensor([-1, 0, 0, -1], dtype=torch.int32, device=dev).expand_as(extra))
+        # unused hub slots -> {-1, 0, 0, -1}; built from device-side fills (no host->device copy: this runs inside captured steps)
+        live = hv.repeat_interleave(S - 1)
+        neg = torch.full_like(live, -1, dtype=torch.int32)
+        zero = torch.zeros_like(neg)
+        extra = torch.where(live.unsqueeze(1), extra, torch.stack([neg, zero, zero, neg], 1))
         items = torch.cat([base.to(torch.int32), extra.to(torch.int32)]).contiguous()
         long_rows = torch.stack([row_e[:, 0], hslot[:, 0] * S, torch.full((H,), S, dtype=torch.int32, device=dev),
                                  torch.zeros(H, dtype=torch.int32, device=dev)], 1).contiguous()
