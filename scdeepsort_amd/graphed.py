@@ -164,6 +164,13 @@ class GraphedShardedForward:
                 begin()
                 self.logits = self.engine.forward(self.feats_g, self.feats_c, gather_logits=self.gather)
                 end()
+            except BaseException:
+                if torch.cuda.is_current_stream_capturing():       # never leave the stream in capture mode behind an error
+                    try:
+                        cur["g"].capture_end()
+                    except Exception:
+                        pass
+                raise
             finally:
                 D.COLLECTIVE_HOOK = None
         torch.cuda.current_stream(self.device).wait_stream(side)

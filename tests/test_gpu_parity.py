@@ -2132,3 +2132,37 @@ def test_joint_projection_of_one_feature_table_matches_separate_projections():
     assert (one - two).abs().max().item() < 2e-6 and (one - out_grad.detach()).abs().max().item() < 2e-6
     m.JOINT_PROJECTION_MAX_ROWS = 100
     assert m._adjacent_rows(f[:120], f[120:]) is None
+
+
+def test_device_built_transpose_cuts_only_the_hub_source():
+    """the source-major (transposed) copy of a device-built block - the backward structure of sampled training - cuts only
+    sources longer than the chunk (here ONE hub gene drawn by all 3000 seed cells) into parts on static hub slots; every other source
+    keeps one item and no partial rows.  K2 over it against a dense evaluation of the same block."""
+    from scdeepsort_amd import ops
+    from scdeepsort_amd.sampler import sample_block
+    rng = np.random.default_rng(3)
+    C, G, D = 3000, 50, 32
+    m = np.zeros((C, G), bool); m[:, 0] = True
+    for r in range(C):
+        m[r, rng.choice(np.arange(1, G), 3, replace=False)] = True
+    expr = sp.csr_matrix(np.where(m, rng.uniform(0.5, 7, (C, G)), 0).astype(np.float32))
+    g = sda.CellGeneGraph.from_expression(expr, device=DEV)
+    blk = sample_block(g.cg, torch.arange(C, device=DEV), 8, torch.Generator(device=DEV).manual_seed(1))   # k >= deg + 1: every edge drawn
+    csr = blk.csr
+    t = csr.transposed()
+    lens = (t.rowptr[1:] - t.rowptr[:-1]).cpu().numpy()
+    assert lens[0] == C and lens[1:].max() < t.plan.chunk
+    items = t.plan.items.cpu().numpy()
+    live = items[items[:, 0] >= 0]
+    assert (live[:, 0] == 0).sum() >= 2 and all((live[:, 0] == s).sum() == 1 for s in range(1, G))   # only the hub is cut
+    assert t.plan.n_partials <= 8 * max(1, csr.nnz // t.plan.chunk)                                   # not G x 8 partial rows
+    alpha = torch.rand(G + 2, device=DEV) + 0.5
+    gr = torch.randn(C, D, device=DEV); h_src = torch.randn(G, D, device=DEV)
+    dal = torch.zeros(G + 2, device=DEV)
+    dh = ops.agg_bwd_src(csr, alpha, sda.SRC_IS_GENE, gr, h_src, dal)
+    A = torch.zeros(C, G, dtype=torch.float64, device=DEV)
+    rows = torch.repeat_interleave(torch.arange(C, device=DEV), (csr.rowptr[1:] - csr.rowptr[:-1]).long())
+    A[rows, csr.col.long()] = csr.val.double()
+    T = A.t() @ (gr.double() * csr.inv_deg.double()[:, None])
+    np.testing.assert_allclose(dh.cpu().numpy(), (alpha[:G, None].double() * T).cpu().numpy(), atol=2e-4, rtol=1e-5)
+    np.testing.assert_allclose(dal[:G].cpu().numpy(), (h_src.double() * T).sum(1).cpu().numpy(), atol=5e-4, rtol=1e-5)
