@@ -2166,3 +2166,32 @@ def test_device_built_transpose_cuts_only_the_hub_source():
     T = A.t() @ (gr.double() * csr.inv_deg.double()[:, None])
     np.testing.assert_allclose(dh.cpu().numpy(), (alpha[:G, None].double() * T).cpu().numpy(), atol=2e-4, rtol=1e-5)
     np.testing.assert_allclose(dal[:G].cpu().numpy(), (h_src.double() * T).sum(1).cpu().numpy(), atol=5e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize("route", ["row_wave", "tiled"])
+@pytest.mark.parametrize("seeded", [False, True])
+def test_three_layer_model_matches_oracle(route, seeded, monkeypatch):
+    """`--n_layers 3` (train.py:139 takes any depth): logits of a 3-layer forward - full graph and a seed batch (only the last
+    two layers are restricted to the seeds' closure), row-wave and LDS-streamed route (alpha-folded hand-over below the last
+    layer) - and the gradients of a seed-batch / full-batch step against the oracle's NodeFlow emulation."""
+    from scdeepsort_amd import ops
+    c = small_case(cells=160, genes=70, dim=20, hidden=12, n_classes=4, n_layers=3, seed=31, test_cells=10)
+    sd = O.init_params(20, 12, 4, 3, 70, seed=9)
+    rg = O.build_reference_graph(c["expr"], c["support_mask"])
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
+    monkeypatch.setattr(ops, "TILED_MIN_WORK", 1 if route == "tiled" else None)
+    ids = np.array([70 + i for i in (0, 7, 33, 3, 150, 159, 42)]) if seeded else np.arange(70, 70 + 160)
+    seeds = torch.from_numpy(ids).to(DEV) if seeded else None
+    m = make_model(sd, 20, 12, 4, 3, 70)
+    with torch.no_grad():
+        got = m(g, dev(c["feats"]), seeds=seeds)
+    want = O.nodeflow_forward(sd, rg, torch.from_numpy(c["feats"]), ids, 3).numpy()
+    np.testing.assert_allclose(got.cpu().numpy(), want, atol=TOL)
+    labels = torch.from_numpy(np.arange(len(ids)) % 4)
+    loss, grads, _ = O.loss_and_grads(sd, rg, torch.from_numpy(c["feats"]), ids, labels, 3)
+    m.train()
+    l = sda.cross_entropy_sum(m(g, dev(c["feats"]), seeds=seeds), labels.to(DEV))
+    l.backward()
+    assert l.item() == pytest.approx(float(loss), rel=1e-5)
+    for k, p in m.named_parameters():
+        np.testing.assert_allclose(p.grad.cpu().numpy(), grads[k].numpy(), atol=2e-4, rtol=1e-3, err_msg=k)

@@ -309,3 +309,17 @@ def test_c_port_matches_numpy_restatement(blocked):
     got = CO.forward(sd, cg, c["feats"], 2, order="project_first_blocked" if blocked else "project_first")
     np.testing.assert_allclose(got, want, atol=2e-5)
     np.testing.assert_allclose(CO.forward(sd, cg, c["feats"], 2), want, atol=2e-5)       # the reference's aggregate-first order
+
+
+def test_two_formulations_agree_at_three_layers():
+    """`--n_layers 3`: the edge-list NodeFlow emulation (gnn.py:47-68 literally) and the CSR full-graph formulation agree, on
+    a predict graph with test cells (the GPU test of the 3-layer model is checked against the former)."""
+    from conftest import small_case
+    c = small_case(cells=160, genes=70, dim=20, hidden=12, n_classes=4, n_layers=3, seed=31, test_cells=10)
+    sd = O.init_params(20, 12, 4, 3, 70, seed=9)
+    rg = O.build_reference_graph(c["expr"], c["support_mask"])
+    a = O.nodeflow_forward(sd, rg, torch.from_numpy(c["feats"]), np.arange(70, 230), 3).numpy()
+    b = O.csr_forward(sd, O.build_csr_graph(c["expr"], c["support_mask"]), c["feats"], 3)
+    np.testing.assert_allclose(a, b, atol=2e-6)
+    sub = O.nodeflow_forward(sd, rg, torch.from_numpy(c["feats"]), np.array([75, 229, 100]), 3).numpy()
+    np.testing.assert_allclose(sub, b[[5, 159, 30]], atol=2e-6)           # a seed batch sees the same 3-hop closure
