@@ -2195,3 +2195,38 @@ def test_three_layer_model_matches_oracle(route, seeded, monkeypatch):
     assert l.item() == pytest.approx(float(loss), rel=1e-5)
     for k, p in m.named_parameters():
         np.testing.assert_allclose(p.grad.cpu().numpy(), grads[k].numpy(), atol=2e-4, rtol=1e-3, err_msg=k)
+
+
+@pytest.mark.parametrize("tiled", [False, True])
+def test_sharded_branch_with_three_layers(tiled, monkeypatch):
+    """The sharded branch (one shard holding every cell, no process group: the N > 1 code path with the collectives skipped) at
+    `n_layers = 3`: two gene<-cell exchanges, the alpha-folded hand-over only below the LAST layer; forward and full-batch
+    training gradients equal to the plain model's."""
+    from scdeepsort_amd import ops, synthetic as S
+    from scdeepsort_amd.sharded import ShardedWgnn
+    G, C, Din, H = 150, 500, 24, 16
+    rp, col, val = S.synth_expression(C, G, 0.1, device=DEV)
+    torch.manual_seed(4)
+    m = sda.GNN(Din, H, 4, 3, G, activation=F.relu).to(DEV)
+    with torch.no_grad():
+        m.alpha.uniform_(0.5, 1.5)
+    feats = S.synth_features(G + C, Din, device=DEV)
+    labels = (torch.arange(C, device=DEV) % 4).long()
+    monkeypatch.setattr(ops, "TILED_MIN_WORK", 1 if tiled else None)
+    g1 = sda.CellGeneGraph.from_device_csr(rp, col, val, G)
+    m.eval()
+    with torch.no_grad():
+        want = m(g1, feats)
+    m.train()
+    sda.cross_entropy_sum(m(g1, feats), labels).backward()
+    want_g = {k: p.grad.clone() for k, p in m.named_parameters()}
+    eng = ShardedWgnn.build(m, rp, col, val, G, global_stats=ShardedWgnn.gene_stats(col, val, G))
+    m.eval()
+    with torch.no_grad():
+        got = eng.forward(feats[:G], feats[G:], gather_logits=False)
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), atol=2e-5)
+    opt = torch.optim.SGD(m.parameters(), lr=0.0)
+    eng.train_step(feats[:G], feats[G:], labels, opt)
+    for k, p in m.named_parameters():
+        scale = max(1.0, want_g[k].abs().max().item())
+        assert (p.grad - want_g[k]).abs().max().item() < 3e-4 * scale, k
