@@ -714,7 +714,10 @@ class _LinearReluBigM(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        out = torch._addmm_activation(bias, x, weight.t())
+        try:
+            out = torch._addmm_activation(bias, x, weight.t())
+        except (RuntimeError, TypeError):                          # private torch entry point: fall back to the plain composition
+            out = torch.relu(torch.nn.functional.linear(x, weight, bias))
         ctx.save_for_backward(x, weight, out)
         return out
 
