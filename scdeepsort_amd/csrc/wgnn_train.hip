@@ -127,11 +127,12 @@ __global__ void __launch_bounds__(256) ce_sum_rows(const float* __restrict__ log
         float s = 0.f;
         for (int c = 0; c < C; ++c) s += __expf(x[c] - m);
         const float lse = m + __logf(s);
-        loss = lse - x[y];                                     // -log softmax(x)[y]
+        const bool in_range = y >= 0 && y < C;                 // a label outside [0, C) never indexes the row: NaN, loudly
+        loss = in_range ? lse - x[y] : __builtin_nanf("");     // -log softmax(x)[y]
         if (dlogits) {
             float* d = dlogits + (size_t)r * ld_d;
             const float inv = 1.0f / s;
-            for (int c = 0; c < C; ++c) d[c] = __expf(x[c] - m) * inv - (c == y ? 1.0f : 0.0f);
+            for (int c = 0; c < C; ++c) d[c] = in_range ? __expf(x[c] - m) * inv - (c == y ? 1.0f : 0.0f) : __builtin_nanf("");
         }
     }
     loss = group_sum<64>(loss);

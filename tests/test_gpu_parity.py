@@ -1893,6 +1893,15 @@ def test_cross_entropy_sum_kernel_matches_torch(n, c):
     np.testing.assert_allclose(x.grad.cpu().numpy(), x64.grad.cpu().numpy(), atol=2e-6)
     assert ops.cross_entropy_sum(x.detach(), y).item() == ops.cross_entropy_sum(x.detach(), y).item()
     assert ops.cross_entropy_sum(x[:0], y[:0]).item() == 0.0
+    # a label outside [0, c) is never used as an index: NaN loss, NaN gradient row, the other rows untouched
+    bad = y.clone(); bad[n // 2] = c + 5; bad[0] = -1
+    xb = x.detach().clone().requires_grad_(True)
+    lb = ops.cross_entropy_sum(xb, bad)
+    lb.backward()
+    assert torch.isnan(lb).item() and torch.isnan(xb.grad[n // 2]).all() and torch.isnan(xb.grad[0]).all()
+    keep = torch.ones(n, dtype=torch.bool, device=DEV); keep[n // 2] = False; keep[0] = False
+    if keep.any():
+        np.testing.assert_allclose(xb.grad[keep].cpu().numpy(), 0.5 * x.grad[keep].cpu().numpy(), atol=2e-6)
 
 
 @pytest.mark.parametrize("mode", ["cells", "genes", "plain"])
