@@ -69,6 +69,18 @@ SCR = 92                         # scratch SGPR of the computed branch
 SSLOT = 86                       # scratch SGPR: GPR index of a shared pair's second slot
 SHARED = DEPTH == 1 and not WRL and "noshared" not in ABLATE    # emit the shared-pair stream (see s_step)
 ORDER = os.environ.get("WGNN_GEN_ORDER", "RLAWF")     # order of a step's groups: R(eads) L(readlanes) W(ait) F(mas) A(ddresses)
+NORL = "norl" in ABLATE          # timing only: no per-pair v_readlane (every entry reuses the packed word of the chunk's last pair) -
+                                 # the upper bound of feeding the packed words through the scalar cache instead of the VALU
+NOWT = "nowt" in ABLATE          # timing only: no ds_read_b64 of the pair's weights (stale weight registers)
+SMEM = "smem" in ABLATE          # timing only, with norl,nowt: the cost side of a scalar-cache entry feed - every 4th pair step drains
+                                 # lgkmcnt (SMEM returns out of order: only 0 proves a scalar load landed) and issues one
+                                 # s_load_dwordx16 (8 entries = 4 pairs) from the chunk's own address (operand %[ep], clobbers s[64:79])
+
+
+def smem_refill(p):
+    if not SMEM or p % 4 != 3:
+        return []
+    return ["s_waitcnt lgkmcnt(0)", f"s_load_dwordx16 s[64:79], %[ep], {hex(64 * (p // 4))}"]
 
 
 def wsgpr(p):
@@ -84,6 +96,8 @@ def wreadlanes(p):
 
 def readlanes(p):
     s = sset(p)
+    if NORL:
+        return []
     out = [f"v_readlane_b32 s{s['pk0']}, %[pk], {2 * p}",
            f"v_readlane_b32 s{s['pk1']}, %[pk], {2 * p + 1}"]
     return out
@@ -105,8 +119,7 @@ def reads(p):
     if WRL:
         return [f"ds_read_b128 v[{x0}:{x0 + 3}], v44", f"ds_read_b128 v[{x1}:{x1 + 3}], v45"] + wreadlanes(p)
     return [f"ds_read_b128 v[{x0}:{x0 + 3}], v44",
-            f"ds_read_b128 v[{x1}:{x1 + 3}], v45",
-            f"ds_read_b64 v[{w}:{w + 1}], %[wb] offset:{8 * p}"]
+            f"ds_read_b128 v[{x1}:{x1 + 3}], v45"] + ([] if NOWT else [f"ds_read_b64 v[{w}:{w + 1}], %[wb] offset:{8 * p}"])
 
 
 def fmas(p):
@@ -142,6 +155,8 @@ def fmas(p):
 
 
 def s_readlanes(p):
+    if NORL:
+        return []
     return [f"v_readlane_b32 s{sset(p)['pk0']}, %[pk], {2 * p}"]
 
 
@@ -152,8 +167,7 @@ def s_addresses(p):
 def s_reads(p):
     x0, _ = xreg(p)
     w = wreg(p)
-    return [f"ds_read_b128 v[{x0}:{x0 + 3}], v44",
-            f"ds_read_b64 v[{w}:{w + 1}], %[wb] offset:{8 * p}"]
+    return [f"ds_read_b128 v[{x0}:{x0 + 3}], v44"] + ([] if NOWT else [f"ds_read_b64 v[{w}:{w + 1}], %[wb] offset:{8 * p}"])
 
 
 def s_fmas(p):
@@ -180,8 +194,8 @@ def s_step(p):
     R = s_reads(p + 1) if p + 1 < N_PAIRS else []
     L = s_readlanes(p + 2) if p + 2 < N_PAIRS else []
     A = s_addresses(p + 2) if p + 2 < N_PAIRS else []
-    W = [f"s_waitcnt lgkmcnt({2 * min(1, N_PAIRS - 1 - p)})"]
-    return out + R + L + A + W + s_fmas(p)
+    W = [f"s_waitcnt lgkmcnt({(1 if NOWT else 2) * min(1, N_PAIRS - 1 - p)})"]
+    return out + R + L + A + W + s_fmas(p) + smem_refill(p)
 
 
 def step(p):
@@ -191,7 +205,7 @@ def step(p):
     L = readlanes(p + DEPTH + 1) if p + DEPTH + 1 < N_PAIRS else []
     A = addresses(p + DEPTH + 1) if p + DEPTH + 1 < N_PAIRS else []
     ahead = min(DEPTH, N_PAIRS - 1 - p)               # pairs fetched after pair p
-    W = [] if "nords" in ABLATE else [f"s_waitcnt lgkmcnt({(2 if WRL else 3) * ahead})"]
+    W = [] if "nords" in ABLATE else [f"s_waitcnt lgkmcnt({(2 if (WRL or NOWT) else 3) * ahead})"]
     F = fmas(p)
     parts = dict(R=R, L=L, A=A, W=W, F=F)
     if ORDER == "interleave":                         # FMAs of the two entries around the scalar work
@@ -200,6 +214,7 @@ def step(p):
     else:
         for k in ORDER:
             out += parts[k]
+    out += smem_refill(p)
     if "xrl" in ABLATE:
         out += ["v_readlane_b32 s86, %[pk], 3", "v_readlane_b32 s86, %[pk], 5"]
     if "xvmov" in ABLATE:
@@ -216,6 +231,10 @@ def step(p):
 def pre(p0):
     """Warm-up for a chunk whose first pair is p0: what the DEPTH+1 steps before step p0 would do, minus their FMAs."""
     out = [f".Lw4_pre{p0}_%=:"]
+    if NORL:                                          # all three scalar sets: the chunk's last pair (always present)
+        for q in range(DEPTH + 2):
+            s = sset(q)
+            out += [f"v_readlane_b32 s{s['pk0']}, %[pk], 62", f"v_readlane_b32 s{s['pk1']}, %[pk], 63"]
     for k in range(DEPTH + 1):
         if p0 + k < N_PAIRS:
             out += readlanes(p0 + k)
@@ -252,6 +271,8 @@ def main(path):
         for p in range(1, N_PAIRS):
             lines += s_step(p)
         lines.append(".Lw4_end_%=:")
+    if SMEM:
+        lines.append("s_waitcnt lgkmcnt(0)")
     body = "".join(f'    "{ln}\\n\\t"\n' for ln in lines)
     with open(path, "w") as f:
         f.write("// GENERATED by gen_flat_asm.py - do not edit.  See that file for the register contract.\n")
