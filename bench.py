@@ -222,6 +222,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
+            from scdeepsort_amd import dist as wdist
+            wdist.reserve_comm_cus()                     # the communicator's channels = the CUs the tile geometry leaves free
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
@@ -394,6 +396,7 @@ def main():
         per_gpu = [None] * world
         dist.all_gather_object(per_gpu, mine)
         comm = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "shared_device": share,
+                "cus_left_to_the_communicator": sda.dist.COMM_CUS, "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"),
                 "collectives_per_step": "1 all-reduce [G,H] (genes<-cells partial sums) + 1 all-gather of the logits"}
         roofline["per_gpu"] = per_gpu
         roofline["aggregate_peak_GBs"] = HBM_PEAK_GBS * (1 if share else world)

@@ -34,6 +34,9 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("WGNN_BACKEND", "nccl")
         kw = dict(device_id=torch.device("cuda", local)) if backend == "nccl" else {}
+        if backend == "nccl":
+            from scdeepsort_amd import dist as wdist
+            wdist.reserve_comm_cus()
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)

@@ -20,6 +20,8 @@ gloo; the product binds it to the HIP operators.
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass
 from typing import Callable, Optional, Sequence, Tuple
 
@@ -60,6 +62,23 @@ def comm_active() -> bool:
 # the capturing object for the duration of the capture - ends the current graph segment, runs ``fn`` eagerly, remembers it
 # for replay and opens the next segment.
 COLLECTIVE_HOOK: Optional[Callable] = None
+
+
+# CUs a rank leaves to the communicator while a data-path collective is in flight next to a tile pass.  RCCL runs one
+# 256-thread workgroup per channel; a tile workgroup needs a whole CU, and the shard geometries fill the chip in ONE round
+# (N = 8: 61 x 4 = 244 tiles, N = 4: 121 x 2, N = 2: 256 x 1), so every CU a channel holds sends a tile to a second round:
+# measured with a spin kernel standing in for the communicator (scratch/comm_contention*.py), the cells<-genes pass of a
+# rank's shard takes +55 .. +65 % next to 16 or 32 held CUs, while a geometry for 224 CUs costs -2 .. +5 % when nothing else
+# runs and is immune up to 32 held CUs.  Applied to the pass that overlaps the [G, H] all-reduce (sharded.ShardedWgnn.build).
+COMM_CUS = int(os.environ.get("WGNN_COMM_CUS", "32"))
+
+
+def reserve_comm_cus() -> None:
+    """Call BEFORE ``init_process_group("nccl")``: caps the communicator at ``COMM_CUS`` channels (RCCL reads
+    NCCL_MAX_NCHANNELS at communicator creation; one channel = one workgroup = one CU taken from the tile kernel), so that
+    the CUs the tile geometry leaves free are the CUs the collective uses.  A value the user exported wins."""
+    if COMM_CUS > 0:
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(COMM_CUS))
 
 
 def _issue(fn: Callable):

@@ -184,6 +184,9 @@ class AggCsr:
     # ell_cnt[i]); rowptr holds the slot starts, the plan's items carry the real ranges.  Row-wave kernels only.
     ell_k: int = 0
     ell_cnt: Optional[torch.Tensor] = field(default=None, repr=False)
+    # CUs the tile kernel may count on for a ONE-ROUND launch of this operand (see tile_plan): a rank of a sharded job whose
+    # pass runs next to an in-flight collective leaves the communicator's workgroups their CUs (sharded.ShardedWgnn.build)
+    cu_budget: int = 256
 
     @property
     def nnz(self) -> int:
@@ -238,9 +241,16 @@ class AggCsr:
         off the plan like the forward, and were measured that way (training step 10.7 -> 10.1 -> 9.9 ms in round 3)."""
         if self._tile_plan is None:
             self._tile_plan = {}
-        key = (block_rows, TILE_LOADER_WAVES if loaders is None else loaders, TILE_SHARED_PAIRS)
+        key = (block_rows, TILE_LOADER_WAVES if loaders is None else loaders, TILE_SHARED_PAIRS, self.cu_budget)
         if key not in self._tile_plan:
-            self._tile_plan[key] = build_tile_plan(self, None, None, block_rows=block_rows, n_loaders=key[1])
+            tp = build_tile_plan(self, None, None, n_cus=self.cu_budget, block_rows=block_rows, n_loaders=key[1])
+            if self.cu_budget < 256 and tp.n_tiles > self.cu_budget:
+                # A tile workgroup takes a whole CU (16 waves x 128 VGPRs, 160 KB LDS).  In a ONE-round launch every CU held
+                # by another kernel pushes a tile into a second round (+55 .. +65 % per pass next to 16 - 32 held CUs,
+                # profiles/r04_issue_analysis.md section 10); a launch of several rounds re-balances by itself, and shrinking
+                # its rounds would only cost the uncontended case - it keeps the full chip.
+                tp = build_tile_plan(self, None, None, block_rows=block_rows, n_loaders=key[1])
+            self._tile_plan[key] = tp
         return self._tile_plan[key]
 
     @property

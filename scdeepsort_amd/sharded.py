@@ -74,6 +74,11 @@ class ShardedWgnn:
             gc._t = None
             gc._tile_plan = None
             world = max(world, 2)
+            # the cells<-genes pass of layer 1 runs while the [G, H] all-reduce of the gene partial sums is in flight
+            # (dist.sharded_forward): its one-round tile geometry leaves the communicator's workgroups their CUs
+            # (dist.COMM_CUS).  The genes<-cells pass only ever meets the short logits all-gather of the previous step and
+            # keeps the whole chip (a 224-CU geometry costs it +15 %: two column splits instead of three).
+            g.cg.cu_budget = max(64, 256 - D.COMM_CUS)
         sizes, pad_nnz = None, None
         if D.comm_active():
             import torch.distributed as tdist

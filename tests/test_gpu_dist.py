@@ -40,6 +40,8 @@ def _worker(rank, world, port, out_dir, hidden, dropout, backend=BACKEND, force=
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     if backend == "nccl":
+        D.reserve_comm_cus()                                        # the production sequence: channel cap, then the communicator
+        assert os.environ["NCCL_MAX_NCHANNELS"] == str(D.COMM_CUS)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     else:
         dist.init_process_group(backend, rank=rank, world_size=world)

@@ -446,6 +446,10 @@ def test_simulated_two_shards_match_unsharded():
         g_deg, g_sum = stats[0][0] + stats[1][0], stats[0][1] + stats[1][1]
         eng = [ShardedWgnn.build(m, r_, c_, v_, G, global_stats=(g_deg, g_sum)) for _, _, r_, c_, v_ in shards]
         assert all(e.world == 2 for e in eng)
+        # a rank's cells<-genes operand leaves the communicator its CUs (one-round tile geometry within 256 - COMM_CUS);
+        # the gene side and the single-GPU graph keep the whole chip
+        assert all(e.graph.cg.cu_budget == 224 and e.graph.gc.cu_budget == 256 for e in eng) and full.cg.cu_budget == 256
+        assert all(e.graph.cg.tile_plan(78).n_tiles <= 224 for e in eng)
         W1, b1 = m.layers[0].fc_neigh.weight, m.layers[0].fc_neigh.bias
         W2, b2 = m.layers[1].fc_neigh.weight, m.layers[1].fc_neigh.bias
         h_g = feats[:G]
@@ -462,6 +466,30 @@ def test_simulated_two_shards_match_unsharded():
     e1 = ShardedWgnn.build(m, rp, col, val, G)
     with torch.no_grad():
         assert torch.equal(e1.forward(feats[:G], feats[G:]), want)
+
+
+def test_budgeted_tile_geometry_matches_full_chip_geometry():
+    """The N = 8 shard of the cfg3 job (12 500 cells x 20 000 genes): the cells<-genes pass on the geometry that leaves 32 CUs
+    to the communicator (dist.COMM_CUS, AggCsr.cu_budget) against the full-chip geometry and against the row-wave kernel."""
+    from scdeepsort_amd import synthetic as S, ops
+    G, C, D = 20_000, 12_500, 256
+    rp, col, val = S.synth_expression(C, G, 0.04, device=DEV)
+    g = sda.CellGeneGraph.from_device_csr(rp, col, val, G)
+    alpha = torch.rand(G + 2, device=DEV) + 0.5
+    hg = S.synth_features(G, D, device=DEV); hc = S.synth_features(C, D, seed=3, device=DEV)
+    kb = ops.tiled_block_rows(D)
+    full = g.cg.tile_plan(kb)
+    g.cg.cu_budget = 224
+    lean = g.cg.tile_plan(kb)
+    assert 224 < full.n_tiles <= 256 and lean.n_tiles <= 224 and lean is not full
+    a = ops.agg_fwd_tiled(g.cg, full, alpha, sda.SRC_IS_GENE, G + 1, hg, hc)
+    b = ops.agg_fwd_tiled(g.cg, lean, alpha, sda.SRC_IS_GENE, G + 1, hg, hc)
+    saved, ops.TILED_MIN_WORK = ops.TILED_MIN_WORK, None
+    try:
+        ref = ops.agg_fwd(g.cg, alpha, sda.SRC_IS_GENE, G + 1, hg, hc)
+    finally:
+        ops.TILED_MIN_WORK = saved
+    assert float((a - b).abs().max()) < 2e-6 and float((b - ref).abs().max()) < 2e-5
 
 
 def test_cell_features_through_k1():

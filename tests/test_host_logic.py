@@ -179,6 +179,41 @@ def test_plan_heuristics():
     assert auto_tile_geometry(764_741, 20_000, rows_cap=240) == (3328, 1)
 
 
+def test_cu_budget_of_the_pass_that_overlaps_a_collective():
+    """A rank's cells<-genes pass runs next to the in-flight [G, H] all-reduce: its ONE-round geometry leaves the communicator
+    its CUs (dist.COMM_CUS; every tile workgroup needs a whole CU).  Shards of the cfg3 job at N = 2 / 4 / 8 fit 224 CUs; an
+    operand that needs several rounds anyway keeps the whole chip."""
+    from scdeepsort_amd import dist as D, graph as GR
+    from scdeepsort_amd.graph import auto_tile_geometry
+    assert D.COMM_CUS == 32
+    for rows, nnz in ((12_500, 9_900_000), (25_000, 19_800_000), (50_000, 39_800_000)):
+        full = auto_tile_geometry(rows, 20_000, 256, nnz, rows_cap=240)
+        lean = auto_tile_geometry(rows, 20_000, 224, nnz, rows_cap=240)
+        assert 224 < full[0] * full[1] <= 256 and 200 <= lean[0] * lean[1] <= 224
+        assert lean[0] * 240 >= rows                                   # the rows still fit the computing waves' accumulators
+    rng = np.random.default_rng(5)
+    A = (rng.random((900, 700)) < 0.05) * rng.uniform(0.5, 2.0, (900, 700))
+    csr = _cpu_agg_csr(A)
+    one = csr.tile_plan(32)
+    csr.cu_budget = 3                       # 900 rows need >= 4 tiles: more than one round of the budget -> the full-chip plan
+    assert csr.tile_plan(32).n_tiles == one.n_tiles
+    csr.cu_budget = 224                     # fits: a plan of its own (cached under its own key), within the budget
+    assert csr.tile_plan(32).n_tiles <= 224 and len(csr._tile_plan) == 3
+    # the channel cap handed to RCCL matches the CUs left free; a value the user exported wins
+    import os
+    saved = os.environ.pop("NCCL_MAX_NCHANNELS", None)
+    try:
+        D.reserve_comm_cus()
+        assert os.environ["NCCL_MAX_NCHANNELS"] == "32"
+        os.environ["NCCL_MAX_NCHANNELS"] = "8"
+        D.reserve_comm_cus()
+        assert os.environ["NCCL_MAX_NCHANNELS"] == "8"
+    finally:
+        os.environ.pop("NCCL_MAX_NCHANNELS", None)
+        if saved is not None:
+            os.environ["NCCL_MAX_NCHANNELS"] = saved
+
+
 def _cpu_agg_csr(A):
     """AggCsr over CPU tensors (the tile-plan builder is pure index arithmetic and runs on any device)."""
     import scipy.sparse as sp
