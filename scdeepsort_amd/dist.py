@@ -20,6 +20,7 @@ gloo; the product binds it to the HIP operators.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 
 from dataclasses import dataclass
@@ -153,6 +154,8 @@ class LocalOps:
     fold_alpha_ok: Optional[Callable] = None       # (width, n_seed_rows | None) -> bool: genes_finish(..., scale_out=True) may write the
                                #  gene rows alpha-folded and cells_mean_linear(..., prescaled=True) reads them as its source
                                #  table without a scale launch (HIP binding only)
+    overlapped: Optional[Callable] = None          # () -> context manager around the cells<-genes pass that runs next to the in-flight
+                               #  all-reduce (HIP binding at N > 1: that pass plans its tiles for the CUs the communicator leaves)
 
 
 def dropout_mask(shape, p: float, generator: Optional[torch.Generator], device, dtype=torch.float32) -> torch.Tensor:
@@ -213,7 +216,8 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
             # cells<-genes pass (row-independent, no communication) computes
             overlap = COLLECTIVE_HOOK is None           # (a segmented capture runs the collective synchronously, now and at replay)
             work = _issue(lambda: dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=overlap)) if comm_active() else None
-            new_c = ops.cells_layer(p_g, p_c, b, relu) if rows is None else ops.cells_layer(p_g, p_c, b, relu, rows, False)
+            with (ops.overlapped() if (overlap and ops.overlapped is not None) else contextlib.nullcontext()):
+                new_c = ops.cells_layer(p_g, p_c, b, relu) if rows is None else ops.cells_layer(p_g, p_c, b, relu, rows, False)
             if work is not None:
                 work.wait()                             # stream-level dependency on GPU backends, no host sync
         # the gene rows below a cells-only, aggregate-first last layer are only read as that layer's alpha-folded source table

@@ -6,6 +6,8 @@ With ``world_size == 1`` it degenerates to the plain single-GPU ``GNN.forward``.
 """
 from __future__ import annotations
 
+import contextlib
+
 from typing import Optional
 
 import torch
@@ -22,6 +24,11 @@ class ShardedWgnn:
     def __init__(self, model: GNN, graph: CellGeneGraph, world: int, shard_sizes=None, pad_nnz: Optional[int] = None,
                  seed: int = 0):
         self.model, self.graph, self.world = model, graph, world
+        # A cells<-genes pass that runs while the [G, H] all-reduce of the gene partial sums is in flight (dist.sharded_forward,
+        # no-grad path) plans its ONE-round tile geometry for the CUs the communicator's workgroups leave (dist.COMM_CUS);
+        # every other pass - the last layer, training (synchronous collectives), the gene side (it only ever meets the short
+        # logits all-gather of the previous step, and its best 224-CU geometry costs +15 %) - keeps the whole chip.
+        self.overlap_cu_budget = max(64, 256 - D.COMM_CUS) if world > 1 else 256
         self.shard_sizes = shard_sizes          # cells per rank (exchanged once at build): sync-free logits concat
         # the zero-padding of narrow hidden widths must not depend on the LOCAL shard size: the [G, Hp] partial sums and
         # the flat gradient bucket are all-reduced, so every rank must carry the same Hp.  ``pad_nnz`` = max over ranks.
@@ -74,11 +81,6 @@ class ShardedWgnn:
             gc._t = None
             gc._tile_plan = None
             world = max(world, 2)
-            # the cells<-genes pass of layer 1 runs while the [G, H] all-reduce of the gene partial sums is in flight
-            # (dist.sharded_forward): its one-round tile geometry leaves the communicator's workgroups their CUs
-            # (dist.COMM_CUS).  The genes<-cells pass only ever meets the short logits all-gather of the previous step and
-            # keeps the whole chip (a 224-CU geometry costs it +15 %: two column splits instead of three).
-            g.cg.cu_budget = max(64, 256 - D.COMM_CUS)
         sizes, pad_nnz = None, None
         if D.comm_active():
             import torch.distributed as tdist
@@ -136,7 +138,16 @@ class ShardedWgnn:
             z = F.relu(z) if relu else z
             return z * a[:G].unsqueeze(1) if scale_out else z
 
-        return D.LocalOps(cells_layer, genes_partial, genes_finish, cells_mean_linear, fold_alpha_ok)
+        @contextlib.contextmanager
+        def overlapped():
+            saved, g.cg.cu_budget = g.cg.cu_budget, self.overlap_cu_budget
+            try:
+                yield
+            finally:
+                g.cg.cu_budget = saved
+
+        return D.LocalOps(cells_layer, genes_partial, genes_finish, cells_mean_linear, fold_alpha_ok,
+                          overlapped if self.overlap_cu_budget != 256 else None)
 
     def _identity(self) -> AggCsr:
         """G x G identity CSR carrying the GLOBAL gene-side 1/(deg+1): lets K1's epilogue finish the all-reduced sums."""

@@ -108,6 +108,34 @@ def _worker(rank, world, port, out_dir, cells=90):
         assert flags == [True]
         np.testing.assert_allclose(l_fold.numpy(), full, atol=1e-6)
         flags.clear()
+        # ---- round 4: `overlapped` wraps exactly the cells<-genes pass that runs next to the in-flight all-reduce (no-grad path):
+        # entered once per non-last layer, never around the last layer's pass, never when the collective is synchronous
+        import contextlib
+        trace = []
+        @contextlib.contextmanager
+        def overlapped():
+            trace.append("enter")
+            try:
+                yield
+            finally:
+                trace.append("exit")
+        def cl(*a, **k):
+            trace.append("cells_layer"); return ops.cells_layer(*a, **k)
+        def cml2(*a, **k):
+            trace.append("cells_mean_linear"); return cml(*a, **k)
+        ops3 = D.LocalOps(cl, ops.genes_partial, gfin, cml2, lambda width, n_seed: True, overlapped)
+        with torch.no_grad():
+            l_ov = D.sharded_forward(weights, None, feats[:G], feats[G + lo:G + hi], ops3, 2, True, sizes)
+        assert trace == ["enter", "cells_layer", "exit", "cells_mean_linear"] and torch.equal(l_ov, l_fold)
+        trace.clear(); flags.clear()
+        D.COLLECTIVE_HOOK = lambda fn: fn()                  # a segmented capture issues the collective synchronously: no overlap
+        try:
+            with torch.no_grad():
+                D.sharded_forward(weights, None, feats[:G], feats[G + lo:G + hi], ops3, 2, True, sizes)
+        finally:
+            D.COLLECTIVE_HOOK = None
+        assert trace == ["cells_layer", "cells_mean_linear"]
+        flags.clear()
         l_grad = D.sharded_forward(weights, None, feats[:G], feats[G + lo:G + hi], ops2, 2, True, sizes)      # grad mode: no fold
         assert flags == [False]
         np.testing.assert_allclose(l_grad.numpy(), full, atol=1e-6)

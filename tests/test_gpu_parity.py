@@ -446,10 +446,12 @@ def test_simulated_two_shards_match_unsharded():
         g_deg, g_sum = stats[0][0] + stats[1][0], stats[0][1] + stats[1][1]
         eng = [ShardedWgnn.build(m, r_, c_, v_, G, global_stats=(g_deg, g_sum)) for _, _, r_, c_, v_ in shards]
         assert all(e.world == 2 for e in eng)
-        # a rank's cells<-genes operand leaves the communicator its CUs (one-round tile geometry within 256 - COMM_CUS);
-        # the gene side and the single-GPU graph keep the whole chip
-        assert all(e.graph.cg.cu_budget == 224 and e.graph.gc.cu_budget == 256 for e in eng) and full.cg.cu_budget == 256
-        assert all(e.graph.cg.tile_plan(78).n_tiles <= 224 for e in eng)
+        # the cells<-genes pass that runs next to the in-flight all-reduce leaves the communicator its CUs (one-round tile
+        # geometry within 256 - COMM_CUS, only inside LocalOps.overlapped()); everything else keeps the whole chip
+        assert all(e.overlap_cu_budget == 224 and e.graph.cg.cu_budget == 256 and e.graph.gc.cu_budget == 256 for e in eng)
+        with eng[0]._ops().overlapped():
+            assert eng[0].graph.cg.cu_budget == 224 and eng[0].graph.cg.tile_plan(78).n_tiles <= 224
+        assert eng[0].graph.cg.cu_budget == 256
         W1, b1 = m.layers[0].fc_neigh.weight, m.layers[0].fc_neigh.bias
         W2, b2 = m.layers[1].fc_neigh.weight, m.layers[1].fc_neigh.bias
         h_g = feats[:G]
@@ -464,6 +466,7 @@ def test_simulated_two_shards_match_unsharded():
     np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), atol=2e-5)
     # world == 1 engine is the plain model
     e1 = ShardedWgnn.build(m, rp, col, val, G)
+    assert e1.overlap_cu_budget == 256 and e1._ops().overlapped is None
     with torch.no_grad():
         assert torch.equal(e1.forward(feats[:G], feats[G:]), want)
 
