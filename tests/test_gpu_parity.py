@@ -2075,6 +2075,56 @@ def test_full_size_properties_cfg5():
     assert (out16 - out32).abs().max().item() < 1e-4
 
 
+def test_full_size_cfg5_sharded_eight_ways_matches_unsharded():
+    """BASELINE cfg5 as the job it names - 764,741 cells sharded 8-way (~95.6k cells, ~7.6e7 non-zeros per rank), fp16-stored
+    features - on one GPU: every rank's partial gene sums are computed through its own `ShardedWgnn` engine (gene side normalised
+    with the GLOBAL statistics) and added where RCCL would all-reduce them; ranks 0 and 7 then run the production
+    `dist.sharded_forward` (overlapped-pass geometry, alpha-folded gene rows, aggregate-first last layer) on that sum, and their
+    logits must equal their rows of the UNSHARDED forward of the whole graph."""
+    import dataclasses
+    from scdeepsort_amd import dist as D, ops, synthetic as S
+    from scdeepsort_amd.sharded import ShardedWgnn
+    cfg = S.CONFIGS["cfg5"]
+    G, C, H, N = cfg.genes, cfg.cells, cfg.hidden, 8
+    rp, col, val = S.synth_expression(C, G, cfg.density, device=DEV)
+    torch.manual_seed(5)
+    m = sda.GNN(cfg.dense_dim, H, cfg.n_classes, 2, G, activation=F.relu).to(DEV).eval()
+    feats = S.synth_features(G + C, cfg.dense_dim, device=DEV, dtype=torch.float16)
+    feats_g, feats_c = feats[:G], feats[G:]
+    with torch.no_grad():
+        m.alpha.uniform_(0.5, 1.5)
+        g = sda.CellGeneGraph.from_device_csr(rp, col, val, G)
+        want = m(g, feats)
+        del g
+        stats = ShardedWgnn.gene_stats(col, val, G)
+        W1 = m.layers[0].fc_neigh.weight
+
+        def shard(r):
+            lo, hi = D.shard_range(C, r, N)
+            b, e = int(rp[lo]), int(rp[hi])
+            eng = ShardedWgnn.build(m, (rp[lo:hi + 1] - rp[lo]).clone(), col[b:e].clone(), val[b:e].clone(), G, global_stats=stats)
+            assert eng.world > 1 and eng.overlap_cu_budget == 224
+            return lo, hi, eng
+
+        total = torch.zeros(G, H, device=DEV)
+        for r in range(N):                                   # <- what the [G, H] all-reduce adds up
+            lo, hi, eng = shard(r)
+            total += eng._ops().genes_partial(ops.linear(feats_c[lo:hi], W1))
+            del eng
+        worst = 0.0
+        for r in (0, N - 1):
+            lo, hi, eng = shard(r)
+            lops = dataclasses.replace(eng._ops(), genes_partial=lambda p_c: total.clone())
+            assert lops.overlapped is not None and lops.fold_alpha_ok(H, None)
+            got = D.sharded_forward(eng._weights(), None, feats_g, feats_c[lo:hi], lops, 2, gather_logits=False, linear=ops.linear)
+            assert got.shape == (hi - lo, cfg.n_classes)
+            worst = max(worst, (got - want[lo:hi]).abs().max().item())
+            tp = [k for k in eng.graph.cg._tile_plan]        # both geometries of the cells side were used: overlapped pass, last layer
+            assert {k[-1] for k in tp} == {224, 256}
+            del eng
+    assert worst < 1e-4, worst
+
+
 def test_tuned_gemm_picks_change_speed_not_results():
     """`tuning.use_tuned_gemms()` (PyTorch TunableOp, selection only) routes the dense projections to the library kernels
     recorded per shape in the tracked file: same logits to rounding, and the fp32 projections leave wgnn_linear_fwd for
