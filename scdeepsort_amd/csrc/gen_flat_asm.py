@@ -67,11 +67,13 @@ FMA2 = "fma2" in ABLATE          # v_fma_f32 x4 instead of v_pk_fma_f32 x2 per e
 WRL = "wrl" in ABLATE            # experiment: weights through v_readlane into SGPR pairs instead of the LDS strip
 SCR = 92                         # scratch SGPR of the computed branch
 SSLOT = 86                       # scratch SGPR: GPR index of a shared pair's second slot
-SHARED = DEPTH == 1 and not WRL and "noshared" not in ABLATE    # emit the shared-pair stream (see s_step)
+SHARED = DEPTH == 1 and not WRL and "noshared" not in ABLATE and "halfmodel" not in ABLATE    # emit the shared-pair stream (see s_step)
 ORDER = os.environ.get("WGNN_GEN_ORDER", "RLAWF")     # order of a step's groups: R(eads) L(readlanes) W(ait) F(mas) A(ddresses)
 NORL = "norl" in ABLATE          # timing only: no per-pair v_readlane (every entry reuses the packed word of the chunk's last pair) -
                                  # the upper bound of feeding the packed words through the scalar cache instead of the VALU
 NOWT = "nowt" in ABLATE          # timing only: no ds_read_b64 of the pair's weights (stale weight registers)
+HALF = "halfmodel" in ABLATE     # timing only (D <= 128): the cost structure of a half-wave pipeline - the two entries of a pair share ONE
+                                 # ds_read_b128 (lanes 0-31 one source row, lanes 32-63 the other) and one pair of packed FMAs
 SMEM = "smem" in ABLATE          # timing only, with norl,nowt: the cost side of a scalar-cache entry feed - every 4th pair step drains
                                  # lgkmcnt (SMEM returns out of order: only 0 proves a scalar load landed) and issues one
                                  # s_load_dwordx16 (8 entries = 4 pairs) from the chunk's own address (operand %[ep], clobbers s[64:79])
@@ -118,6 +120,8 @@ def reads(p):
     w = wreg(p)
     if WRL:
         return [f"ds_read_b128 v[{x0}:{x0 + 3}], v44", f"ds_read_b128 v[{x1}:{x1 + 3}], v45"] + wreadlanes(p)
+    if HALF:
+        return [f"ds_read_b128 v[{x0}:{x0 + 3}], v44", f"ds_read_b64 v[{w}:{w + 1}], %[wb] offset:{8 * p}"]
     return [f"ds_read_b128 v[{x0}:{x0 + 3}], v44",
             f"ds_read_b128 v[{x1}:{x1 + 3}], v45"] + ([] if NOWT else [f"ds_read_b64 v[{w}:{w + 1}], %[wb] offset:{8 * p}"])
 
@@ -144,6 +148,11 @@ def fmas(p):
                 f"s_set_gpr_idx_idx s{s['pk1']}",
                 f"v_pk_fma_f32 v[64:65], s[{w1}:{w1 + 1}], v[{x1}:{x1 + 1}], v[64:65] {lo}",
                 f"v_pk_fma_f32 v[66:67], s[{w1}:{w1 + 1}], v[{x1 + 2}:{x1 + 3}], v[66:67] {lo}",
+                "s_set_gpr_idx_off"]
+    if HALF:
+        return [f"s_set_gpr_idx_on s{s['pk0']}, gpr_idx(SRC2,DST)",
+                f"v_pk_fma_f32 v[64:65], {w}, v[{x0}:{x0 + 1}], v[64:65] {lo}",
+                f"v_pk_fma_f32 v[66:67], {w}, v[{x0 + 2}:{x0 + 3}], v[66:67] {lo}",
                 "s_set_gpr_idx_off"]
     return [f"s_set_gpr_idx_on s{s['pk0']}, gpr_idx(SRC2,DST)",
             f"v_pk_fma_f32 v[64:65], {w}, v[{x0}:{x0 + 1}], v[64:65] {lo}",
@@ -205,7 +214,7 @@ def step(p):
     L = readlanes(p + DEPTH + 1) if p + DEPTH + 1 < N_PAIRS else []
     A = addresses(p + DEPTH + 1) if p + DEPTH + 1 < N_PAIRS else []
     ahead = min(DEPTH, N_PAIRS - 1 - p)               # pairs fetched after pair p
-    W = [] if "nords" in ABLATE else [f"s_waitcnt lgkmcnt({(2 if (WRL or NOWT) else 3) * ahead})"]
+    W = [] if "nords" in ABLATE else [f"s_waitcnt lgkmcnt({(2 if (WRL or NOWT or HALF) else 3) * ahead})"]
     F = fmas(p)
     parts = dict(R=R, L=L, A=A, W=W, F=F)
     if ORDER == "interleave":                         # FMAs of the two entries around the scalar work
