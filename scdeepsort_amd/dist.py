@@ -172,7 +172,7 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
                     n_layers: int, gather_logits: bool = True, shard_sizes: Optional[Sequence[int]] = None,
                     async_gather: bool = False, dropout_masks: Optional[Sequence[Tuple[torch.Tensor, torch.Tensor]]] = None,
                     relu: bool = True, linear: Callable = torch.nn.functional.linear,
-                    seeds_local: Optional[torch.Tensor] = None):
+                    seeds_local: Optional[torch.Tensor] = None, pre_aggregate: Optional[Callable] = None):
     """Layer-wise forward over a cell shard.  ``weights`` = list of (W_i, b_i) + (W_out, b_out) last.
     Features may be stored in fp16 (BASELINE cfg5): they are widened on the way into the fp32 projection, i.e. the
     arithmetic is "fp16-rounded inputs, fp32 accumulate".  ``shard_sizes`` (cells per rank, known at graph build)
@@ -180,7 +180,15 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
     concat is left running on the communicator's stream and ``(logits_all, work)`` is returned - the caller waits on
     ``work`` before reading, so the output collection of one batch overlaps the next batch's compute.
     ``dropout_masks[i] = (mask_genes [G,D_i], mask_cells_local [C_p,D_i])``: train-mode dropout on the input rows of
-    layer i (gnn.py:60-64) - the gene mask must be identical on every rank (see :func:`dropout_mask`)."""
+    layer i (gnn.py:60-64) - the gene mask must be identical on every rank (see :func:`dropout_mask`).
+    ``pre_aggregate``: called once, right before the FIRST aggregation launch of this forward (after the first layer's
+    projections): the engine completes the previous forward's in-flight logits concat there, so that the concat runs under
+    the projections (library GEMMs share the chip with the communicator's workgroups) and never next to a tile pass."""
+    def first_aggregation():
+        nonlocal pre_aggregate
+        if pre_aggregate is not None:
+            pre_aggregate()
+            pre_aggregate = None
     h_g, h_c = feats_g, feats_c_local
     compact = False                                     # h_c holds the seeds' rows only (see GNN.embed for the rule)
     folded = False                                      # h_g holds alpha-folded gene rows (written so by genes_finish)
@@ -197,6 +205,7 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
             # the last layer in the reference's literal order (gnn.py:65-66), in training as well (round 4; every step of it is
             # differentiable): no replicated [G, H] x [H, H] projection of the gene rows, forward or backward
             kw = {"prescaled": True} if folded else {}
+            first_aggregation()
             h_c = (ops.cells_mean_linear(h_g, h_c, W, b, relu, **kw) if rows is None
                    else ops.cells_mean_linear(h_g, h_c, W, b, relu, rows, compact, **kw))
             break
@@ -204,6 +213,7 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
             p_g, p_c = linear(h_g, W), linear(h_c, W)
         else:
             p_g, p_c = linear(h_g.to(W.dtype), W), linear(h_c.to(W.dtype), W)
+        first_aggregation()
         if last:                                        # a seed mini-batch only needs its own rows of the last layer
             h_c = ops.cells_layer(p_g, p_c, b, relu) if rows is None else ops.cells_layer(p_g, p_c, b, relu, rows, compact)
             break

@@ -203,12 +203,12 @@ class ShardedWgnn:
     def forward(self, feats_g: torch.Tensor, feats_c_local: torch.Tensor, gather_logits: bool = True,
                 async_gather: bool = False) -> torch.Tensor:
         """Logits of every cell of the job (``gather_logits``) or of this rank's cells.  ``async_gather``: the concat of
-        this call is left in flight (it overlaps the next call's compute); ``wait_gather()`` - called automatically at
-        the start of the next forward - completes it before the returned tensor may be read."""
+        this call is left in flight; ``wait_gather()`` completes it before the returned tensor may be read.  The NEXT forward
+        calls it by itself - after issuing its first layer's projections, before its first aggregation launch: the concat
+        runs under the library GEMMs and never next to a tile pass (whose one-round geometry needs every CU it planned for)."""
         m = self.model
         if self.world == 1:
             return m.linear(m.embed(self.graph, (feats_g, feats_c_local)))
-        self.wait_gather()
         if gather_logits and D.comm_active() and (self.shard_sizes is None or len(self.shard_sizes) != D.world()[1]):
             # an engine constructed directly (not through ``build``, which exchanges the sizes): one exchange, cached -
             # the per-forward concat then needs no size exchange / host read (``dist.sharded_forward`` raises without them)
@@ -218,7 +218,8 @@ class ShardedWgnn:
             tdist.all_gather(every, mine)
             self.shard_sizes = [int(t.item()) for t in every]
         res = D.sharded_forward(self._weights(), None, feats_g, feats_c_local, self._ops(), m.n_layers, gather_logits,
-                                self.shard_sizes, async_gather, self.dropout_masks(feats_g, feats_c_local), self.relu, _linear)
+                                self.shard_sizes, async_gather, self.dropout_masks(feats_g, feats_c_local), self.relu, _linear,
+                                pre_aggregate=self.wait_gather)
         if async_gather:
             res, self._pending = res
         return res

@@ -136,6 +136,20 @@ def _worker(rank, world, port, out_dir, cells=90):
             D.COLLECTIVE_HOOK = None
         assert trace == ["cells_layer", "cells_mean_linear"]
         flags.clear()
+        # ---- round 4: `pre_aggregate` (the engine's wait on the previous forward's in-flight logits concat) fires ONCE, after the
+        # first layer's projections have been issued and before the first aggregation launch
+        trace.clear()
+        def lin(x, W, b=None):
+            trace.append("linear"); return torch.nn.functional.linear(x, W, b)
+        def gp(p_c):
+            trace.append("genes_partial"); return ops.genes_partial(p_c)
+        ops4 = D.LocalOps(cl, gp, gfin, cml2, lambda width, n_seed: True)
+        with torch.no_grad():
+            l_pre = D.sharded_forward(weights, None, feats[:G], feats[G + lo:G + hi], ops4, 2, True, sizes, linear=lin,
+                                      pre_aggregate=lambda: trace.append("pre_aggregate"))
+        assert trace == ["linear", "linear", "pre_aggregate", "genes_partial", "cells_layer", "cells_mean_linear"]
+        assert torch.equal(l_pre, l_fold)
+        flags.clear()
         l_grad = D.sharded_forward(weights, None, feats[:G], feats[G + lo:G + hi], ops2, 2, True, sizes)      # grad mode: no fold
         assert flags == [False]
         np.testing.assert_allclose(l_grad.numpy(), full, atol=1e-6)
