@@ -16,7 +16,7 @@ import torch.nn.functional as F
 from . import dist as D
 from ._lib import DST_IS_GENE, NO_ALPHA, SRC_IS_GENE
 from .gnn import GNN, _is_relu, pad_width
-from .graph import AggCsr, CellGeneGraph, _normalize_on_device, build_plan
+from .graph import AggCsr, CellGeneGraph, build_plan
 from .ops import agg_fwd, cross_entropy_sum, linear as _linear, linear_act, weighted_mean_aggregate, weighted_sum
 
 
