@@ -196,8 +196,8 @@ def main():
                     help="strong (default): ONE cfg-sized job, its cells sharded over the ranks (BASELINE cfg3/cfg4/cfg5); "
                          "weak: every rank owns a cfg-sized shard")
     ap.add_argument("--graphed", choices=("auto", "on", "off"), default="auto",
-                    help="replay the forward as ONE hipGraph launch per step (auto: at N = 1; at N > 1 only with `on`: the captured "
-                         "sharded forward is then timed against eager issue and the faster one runs)")
+                    help="replay the forward as ONE hipGraph launch per step (auto: launch-bound configs, i.e. small graphs at N = 1; "
+                         "at N > 1 only with `on`: the captured sharded forward is then timed against eager issue and the faster one runs)")
     ap.add_argument("--hidden", type=int, default=None, help="override the config's hidden width (e.g. 200, the reference's default "
                                                              "hidden_dim, train.py:137) - a side measurement, not BASELINE's line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -271,11 +271,12 @@ def main():
     # N > 1: "auto" issues the sharded forward EAGERLY - measured faster than the captured graph on the 1-GPU lease (a rank's shard
     # is GPU-bound: profiles/r04_shard_trace.json), and a capture that includes RCCL collectives across real peers cannot be
     # exercised on that lease; `--graphed on` captures it (GraphedShardedForward), times both and runs the faster one.
-    # N = 1: "auto" replays the captured forward at every size (round 4): besides the launch-bound small graphs it is also the
-    # cleaner measurement of the big ones - the timed eager loop carries two HIP events per aggregation launch for the roofline's
-    # per-kernel durations, a replay carries none (those come from the separate eager pass below): cfg3 3.453 / 3.459 ms
-    # replayed vs 3.504 / 3.519 ms eager on the same box, cfg5 equal.
-    graphed = (world == 1 and args.graphed != "off") or (world > 1 and args.graphed == "on")
+    # N = 1: "auto" replays the launch-bound small graphs only.  The big ones are issued eagerly so that the roofline's HIP events sit
+    # INSIDE the timed region, around the very launches that are timed; `--graphed on` replays them too (cfg3: 3.453 / 3.459 ms
+    # replayed vs 3.504 / 3.519 ms eager on one box, 3.599 vs 3.591 on another; cfg5 equal) and then takes the per-kernel durations
+    # from a separate eager pass, reported as `config.eager_ms_per_step`.
+    graphed = (world == 1 and (args.graphed == "on" or (args.graphed == "auto" and cfg.cells * cfg.genes <= 100_000_000))) \
+        or (world > 1 and args.graphed == "on")
     step_fn, launch_desc, launch_calibration = None, "eager", None
     if graphed and world == 1:
         from scdeepsort_amd.graphed import GraphedForward
@@ -301,12 +302,12 @@ def main():
                 launch_desc = f"eager (measured faster than the captured graph: {launch_calibration} ms per step)"
             else:
                 launch_desc += f" (measured faster than eager: {launch_calibration} ms per step)"
-    # the timed region carries no HIP events (two per aggregation launch cost ~1 % of an eager cfg3 step): the roofline's
-    # per-kernel durations come from a second, eager pass of the same K steps outside it
-    dt, dt_local, _, out = timed_steps(engine, feats_g, feats_c, args.steps, args.warmup, world, dev, profile=False, step=step_fn)
+    dt, dt_local, prof, out = timed_steps(engine, feats_g, feats_c, args.steps, args.warmup, world, dev, step=step_fn)
     assert torch.isfinite(out).all()
-    dt_e, _, prof, _ = timed_steps(engine, feats_g, feats_c, args.steps, 1, world, dev)
-    eager_ms = round(dt_e / args.steps * 1e3, 4)         # the same K steps issued eagerly WITH the per-launch events (never `value`)
+    eager_ms = None
+    if graphed:
+        dt_e, _, prof, _ = timed_steps(engine, feats_g, feats_c, args.steps, 1, world, dev)
+        eager_ms = round(dt_e / args.steps * 1e3, 4)
     ms_per_step = dt / args.steps * 1e3
     value = total_cells / (dt / args.steps)
 
