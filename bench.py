@@ -231,7 +231,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     try:                                             # the dense projections are plain library GEMMs: hipBLASLt's fp32 kernels
         torch.backends.cuda.preferred_blas_library("hipblaslt")      # ran ~10 % faster than the default choice on these shapes
-    except Exception:                                                # (scratch/gemm_tune.py, round 2)
+    except Exception:                                                # (profiles/r02_issue_analysis.md)
         pass
 
     import scdeepsort_amd as sda

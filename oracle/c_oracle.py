@@ -49,7 +49,7 @@ def aggregate_blocked(rowptr, col, val, alpha, mode, self_idx, h_src, h_self, ti
     val = np.ascontiguousarray(val, np.float32); alpha = np.ascontiguousarray(alpha, np.float32).ravel()
     h_src = np.ascontiguousarray(h_src, np.float32); h_self = np.ascontiguousarray(h_self, np.float32)
     R, D = h_self.shape
-    if tile_rows is None:          # measured on the GPU box's host (scratch/cpu_blocked_time.py): 128 for the many-row cell side
+    if tile_rows is None:          # measured on the GPU box's host (profiles/r03_issue_analysis.md): 128 for the many-row cell side
         tile_rows = 128 if R >= 40_000 else 256
     out = np.empty((R, D), np.float32)
     pre = np.empty_like(h_src) if mode == 0 else h_src

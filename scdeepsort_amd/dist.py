@@ -68,7 +68,7 @@ COLLECTIVE_HOOK: Optional[Callable] = None
 # CUs a rank leaves to the communicator while a data-path collective is in flight next to a tile pass.  RCCL runs one
 # 256-thread workgroup per channel; a tile workgroup needs a whole CU, and the shard geometries fill the chip in ONE round
 # (N = 8: 61 x 4 = 244 tiles, N = 4: 121 x 2, N = 2: 256 x 1), so every CU a channel holds sends a tile to a second round:
-# measured with a spin kernel standing in for the communicator (scratch/comm_contention*.py), the cells<-genes pass of a
+# measured with a spin kernel standing in for the communicator (profiles/r04_issue_analysis.md §10), the cells<-genes pass of a
 # rank's shard takes +55 .. +65 % next to 16 or 32 held CUs, while a geometry for 224 CUs costs -2 .. +5 % when nothing else
 # runs and is immune up to 32 held CUs.  Applied to the pass that overlaps the [G, H] all-reduce (sharded.ShardedWgnn.build).
 COMM_CUS = int(os.environ.get("WGNN_COMM_CUS", "32"))

@@ -466,7 +466,7 @@ TILE_SHARED_PAIRS = True
 TILE_PAIR_FLAG = -(1 << 31)      # int32 sign bit of an entry's meta word: member of a shared pair
 TILE_PAD_FLAG = 1 << 30          # a zero-weight filler that keeps the pairs at even offsets
 # Few-row operands (one round of column-split tiles): entries per (computing wave, LDS block) from which L loader waves pay
-# (scratch/density_loader.py, cfg3 node counts, density 0.5 .. 8 %, lean loader loop): one loader wave on the gene side wins
+# (profiles/r03_issue_analysis.md: cfg3 node counts, density 0.5 .. 8 %, lean loader loop): one loader wave on the gene side wins
 # from ~30 (0.88 vs 0.97 ms at 37; 0.87 vs 0.79 at 24 - its stream has a floor of ~0.85 ms).  Many-row operands (no column
 # split) gain at every density measured (5 .. 87 entries per wave and block) and are not guarded.
 LOADER_MIN_ENTRIES = {1: 30.0, 2: 16.0, 3: 16.0}
@@ -556,12 +556,12 @@ def _snake(p: torch.Tensor, n: int) -> torch.Tensor:
     return torch.where(r % 2 == 0, q, n - 1 - q)
 
 
-ONE_ROUND_MIN_NNZ = 0               # one round wins or ties at every size measured: 2.0 M edges 62 vs 75 us, 11.9 M even, 39.8 M -20 %, 79.8 M -14 %, 159.8 M -13 % (scratch/geom_rounds.py, cfg2_crossover.py)
+ONE_ROUND_MIN_NNZ = 0               # one round wins or ties at every size measured: 2.0 M edges 62 vs 75 us, 11.9 M even, 39.8 M -20 %, 79.8 M -14 %, 159.8 M -13 % (profiles/r02_issue_analysis.md, r04_issue_analysis.md §4)
 
 
 def auto_tile_geometry(n_rows: int, n_cols: int, n_cus: int = 256, nnz: Optional[int] = None,
                        rows_cap: int = 256) -> Tuple[int, int]:
-    """(n_row_tiles, n_col_splits), from sweeps at 10k..100k cells (``scratch/geom_mid.py``, ``geom_sweep.py``):
+    """(n_row_tiles, n_col_splits), from sweeps at 10k..100k cells (profiles/r01_issue_analysis.md, r02_issue_analysis.md):
     * many rows (>= 40k): whole rounds of ~195..256-row tiles over the CUs, no column split;
     * fewer rows (the gene side; the cell side of small graphs): ~250-row tiles, and the source axis split so that
       hub rows spread over several workgroups and the launch has ~nnz/50k tiles (between 160 and five full rounds)."""
@@ -575,7 +575,7 @@ def auto_tile_geometry(n_rows: int, n_cols: int, n_cus: int = 256, nnz: Optional
     if nnz is not None and nnz >= ONE_ROUND_MIN_NNZ and n_row_tiles <= n_cus:
         # big operands: ONE round of <= n_cus workgroups.  Every extra column split costs one more partial-sum row per
         # destination row (written, then re-read by agg_finalize); at cfg3 the genes<-cells pass went from 80 x 16
-        # tiles / 335 MB of partial sums / 1.42 ms to 85 x 3 / 63 MB / 1.22 ms (scratch/gene_pass_ab.py, round 2).
+        # tiles / 335 MB of partial sums / 1.42 ms to 85 x 3 / 63 MB / 1.22 ms (profiles/r02_issue_analysis.md).
         def one_round(rows_per_tile):
             rt = max(1, -(-n_rows // rows_per_tile))
             sp = max(1, min(n_cus // rt, n_cols // 512 or 1))

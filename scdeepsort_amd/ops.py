@@ -57,7 +57,7 @@ PAD_NARROW_TO_256 = False           # round-1 behaviour (hidden < 256 carried as
 # nnz * max(D, 128) above which the LDS-streamed kernels take a pass.  The tile kernel's time hardly depends on D (it is bound
 # by per-edge instruction issue), the row-wave kernel's gathers scale with it: at BASELINE cfg2's 2.0 M edges a pass costs
 # 60 / 59 us tiled against 62 / 71 us row-wave at D = 128 and 62 / 61 against 100 / 129 us at D = 200 (round 4,
-# scratch/narrow_rows.py) - rounds 1-3 used 5e8 (~2 M edges at D = 256), which left cfg2 and every hidden-200 graph of
+# profiles/r04_issue_analysis.md §4) - rounds 1-3 used 5e8 (~2 M edges at D = 256), which left cfg2 and every hidden-200 graph of
 # that size on the row-wave kernel.
 TILED_MIN_WORK = int(__import__("os").environ.get("WGNN_TILED_MIN_WORK", 250_000_000))
 SEED_FULL_PASS_MIN_FRAC = 0.2       # a seed set of at least this share of the rows of a tile-kernel operand runs the FULL LDS-streamed
