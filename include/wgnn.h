@@ -352,8 +352,10 @@ int wgnn_agg_linear_relu_fwd(const void* rowptr /* as wgnn_agg_fwd */, const int
  * wgnn_ce_sum_fwd_bwd: CrossEntropyLoss(reduction='sum') (train.py:36) over float logits[n_rows, n_classes] and int64 labels:
  *     *loss_sum = sum_r ( logsumexp(logits[r]) - logits[r, labels[r]] ) ;  dlogits[r] = softmax(logits[r]) - onehot(labels[r])
  *   (dlogits may be NULL).  workspace: wgnn_ce_sum_workspace floats.  Deterministic (fixed-order folds, no atomics).
- *   A label outside [0, n_classes) is never used as an index: its row's loss term and dlogits row are NaN (the framework
- *   call this replaces raises a device-side assertion; a kernel that never synchronises cannot, NaN is its loud answer).
+ *   A label of -100 (torch's default ignore_index) contributes 0 to the loss and a zero dlogits row, as in the framework call
+ *   this replaces.  Any other label outside [0, n_classes) - tested on the 64-bit value - is never used as an index: its
+ *   row's loss term and dlogits row are NaN (the framework call raises a device-side assertion; a kernel that never
+ *   synchronises cannot, NaN is its loud answer).  expf / logf, not the fast intrinsics.
  * ------------------------------------------------------------------------- */
 int wgnn_agg_bwd_prepare_workspace(int64_t n_rows, int32_t D, int64_t* floats);
 int wgnn_agg_bwd_prepare(const float* gout, int64_t ld_gout, const float* out, int64_t ld_out,

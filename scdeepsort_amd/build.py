@@ -66,7 +66,8 @@ def flat4_resource_usage() -> dict:
             cur["remarks"][m.group(1).strip()] = m.group(2)
     for name, rec in kernels.items():
         m = re.search(r"^\s*\.name:\s+%s\s*$" % re.escape(name), asm, re.M)
-        md = asm[asm.rfind("- .agpr_count", 0, m.start()) if m else 0: m.start() if m else 0] if m else ""
+        if m is None or f"\n{name}:" not in asm:              # a hipcc whose assembly text this parser does not understand
+            raise RegisterContractError(f"cannot audit {name}: its metadata / body was not found in the assembly")
         # metadata entries of one kernel sit in one YAML map: take the fields around .name
         blk_start = asm.rfind("  - .", 0, m.start())
         blk_end = asm.find("\n  - .", m.end())
@@ -134,8 +135,8 @@ def build(force: bool = False, verbose: bool = False, audit: bool = True) -> Pat
     if audit:                                                # the hand-split register file of agg_tiled_flat4 is a build-time contract
         try:
             audit_flat4()
-        except RegisterContractError:
-            LIB.unlink(missing_ok=True)                      # never leave a library behind that violates it
+        except Exception:                                    # a violated contract OR an audit that could not run (parse error on
+            LIB.unlink(missing_ok=True)                      # another hipcc): never leave an unaudited library behind
             raise
     return LIB
 

@@ -121,18 +121,21 @@ __global__ void __launch_bounds__(256) ce_sum_rows(const float* __restrict__ log
     float loss = 0.f;
     if (r < n_rows) {
         const float* x = logits + (size_t)r * ld;
-        const int y = (int)labels[r];
+        const long long y64 = labels[r];                       // range-checked on the 64-bit value (never truncated first)
+        const bool ignored = y64 == -100;                      // torch's default ignore_index: loss 0, gradient row 0
+        const bool in_range = y64 >= 0 && y64 < (long long)C;  // any other label outside [0, C) never indexes the row: NaN, loudly
+        const int y = in_range ? (int)y64 : 0;
         float m = x[0];
         for (int c = 1; c < C; ++c) m = fmaxf(m, x[c]);
         float s = 0.f;
-        for (int c = 0; c < C; ++c) s += __expf(x[c] - m);
-        const float lse = m + __logf(s);
-        const bool in_range = y >= 0 && y < C;                 // a label outside [0, C) never indexes the row: NaN, loudly
-        loss = in_range ? lse - x[y] : __builtin_nanf("");     // -log softmax(x)[y]
+        for (int c = 0; c < C; ++c) s += expf(x[c] - m);       // expf / logf, not the fast intrinsics: the kernel is HBM-bound and the
+        const float lse = m + logf(s);                         // __logf error (~4e-7 per row) is systematic over 1e5..1e6 summed rows
+        loss = ignored ? 0.f : (in_range ? lse - x[y] : __builtin_nanf(""));     // -log softmax(x)[y]
         if (dlogits) {
             float* d = dlogits + (size_t)r * ld_d;
             const float inv = 1.0f / s;
-            for (int c = 0; c < C; ++c) d[c] = in_range ? __expf(x[c] - m) * inv - (c == y ? 1.0f : 0.0f) : __builtin_nanf("");
+            for (int c = 0; c < C; ++c)
+                d[c] = ignored ? 0.f : (in_range ? expf(x[c] - m) * inv - (c == y ? 1.0f : 0.0f) : __builtin_nanf(""));
         }
     }
     loss = group_sum<64>(loss);

@@ -74,11 +74,17 @@ COLLECTIVE_HOOK: Optional[Callable] = None
 COMM_CUS = int(os.environ.get("WGNN_COMM_CUS", "32"))
 
 
-def reserve_comm_cus() -> None:
-    """Call BEFORE ``init_process_group("nccl")``: caps the communicator at ``COMM_CUS`` channels (RCCL reads
-    NCCL_MAX_NCHANNELS at communicator creation; one channel = one workgroup = one CU taken from the tile kernel), so that
-    the CUs the tile geometry leaves free are the CUs the collective uses.  A value the user exported wins."""
-    if COMM_CUS > 0:
+def reserve_comm_cus(cap_channels: Optional[bool] = None) -> None:
+    """Call BEFORE ``init_process_group("nccl")``.  OPT-IN (round 5): with ``cap_channels=True`` or
+    ``WGNN_CAP_NCCL_CHANNELS=1`` the communicator is capped at ``COMM_CUS`` channels (RCCL reads NCCL_MAX_NCHANNELS at
+    communicator creation; one channel = one workgroup = one CU taken from the tile kernel), so that the CUs the tile
+    geometry leaves free are the CUs the collective uses.  The cap is process-wide - it also limits the gradient SUM
+    all-reduce of training and any other communicator of the process - and its value comes from a spin-kernel stand-in on a
+    1-GPU lease, never from RCCL between two devices: by default nothing is exported and only the tile geometry of the
+    overlapped pass (``COMM_CUS``) applies.  A value the user exported always wins."""
+    if cap_channels is None:
+        cap_channels = os.environ.get("WGNN_CAP_NCCL_CHANNELS", "0") == "1"
+    if cap_channels and COMM_CUS > 0:
         os.environ.setdefault("NCCL_MAX_NCHANNELS", str(COMM_CUS))
 
 
@@ -225,7 +231,9 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
             # the ONE data-path collective (X2) runs on the communicator's stream while this rank's
             # cells<-genes pass (row-independent, no communication) computes
             overlap = COLLECTIVE_HOOK is None           # (a segmented capture runs the collective synchronously, now and at replay)
-            work = _issue(lambda: dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=overlap)) if comm_active() else None
+            # (the thunk is kept for replay by a segmented capture: bind THIS layer's tensor, not the loop variable)
+            work = _issue(lambda part=part, overlap=overlap: dist.all_reduce(part, op=dist.ReduceOp.SUM, async_op=overlap)) \
+                if comm_active() else None
             with (ops.overlapped() if (overlap and ops.overlapped is not None) else contextlib.nullcontext()):
                 new_c = ops.cells_layer(p_g, p_c, b, relu) if rows is None else ops.cells_layer(p_g, p_c, b, relu, rows, False)
             if work is not None:
@@ -234,6 +242,9 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
         Wn = weights[i + 1][0]
         folded = bool(i == n_layers - 2 and ops.fold_alpha_ok is not None and ops.cells_mean_linear is not None
                       and not torch.is_grad_enabled() and dropout_masks is None and Wn.shape[0] == Wn.shape[1] == W.shape[0]
+                      # the consumer's `h_g.dtype == W.dtype` test above must hold for the folded rows, or the last layer would
+                      # take cells_layer and apply alpha a second time (the HIP binding's fold_alpha_ok also demands f32)
+                      and W.dtype == Wn.dtype == p_g.dtype
                       and ops.fold_alpha_ok(W.shape[0], None if seeds_local is None else int(seeds_local.shape[0])))
         h_g = ops.genes_finish(part, p_g, b, relu, scale_out=True) if folded else ops.genes_finish(part, p_g, b, relu)
         h_c = new_c
@@ -249,13 +260,14 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
         if len(set(shard_sizes)) == 1:
             out = torch.empty((ws * logits.shape[0], logits.shape[1]), dtype=logits.dtype, device=logits.device)
             mine, in_flight = logits.contiguous(), async_gather and COLLECTIVE_HOOK is None
-            work = _issue(lambda: dist.all_gather_into_tensor(out, mine, async_op=in_flight))      # X3: inference concat
+            work = _issue(lambda out=out, mine=mine, in_flight=in_flight:
+                          dist.all_gather_into_tensor(out, mine, async_op=in_flight))              # X3: inference concat
             return (out, work) if async_gather else out
         mx = max(shard_sizes)                           # ragged shards: pad to the largest, gather, cut
         pad = torch.zeros(mx, logits.shape[1], dtype=logits.dtype, device=logits.device)
         pad[: logits.shape[0]] = logits
         outs = [torch.empty_like(pad) for _ in range(ws)]
-        _issue(lambda: dist.all_gather(outs, pad))
+        _issue(lambda outs=outs, pad=pad: dist.all_gather(outs, pad))
         cat = torch.cat([o[:n] for o, n in zip(outs, shard_sizes)])
         return (cat, None) if async_gather else cat
     return (logits, None) if async_gather else logits

@@ -201,7 +201,9 @@ class GNN(nn.Module):
         act_ok = layer.norm is None and (layer.activation is None or _is_relu(layer.activation))
         H = layer.fc_neigh.weight.shape[0]
         Hp = self._pad_width(g, H)
-        return (getattr(self, "fold_alpha", True) and act_ok and self._project_first(layer, True) and not self._project_first(nxt, False)
+        f32 = layer.fc_neigh.weight.dtype == torch.float32 and nxt.fc_neigh.weight.dtype == torch.float32   # the consumer of a
+        # folded table is the f32 tile route only (a .half() model would otherwise meet the row-wave guard)
+        return (getattr(self, "fold_alpha", True) and f32 and act_ok and self._project_first(layer, True) and not self._project_first(nxt, False)
                 and Hp == H and nxt.fc_neigh.weight.shape[1] == H
                 and _ops.will_run_tiled(g.cg, H, None if cell_rows is None else int(cell_rows.shape[0])))
 

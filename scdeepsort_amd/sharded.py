@@ -120,8 +120,9 @@ class ShardedWgnn:
             return linear_act(z, W, b, relu)
 
         def fold_alpha_ok(width, n_seed_rows):
-            from . import ops as _o
-            return _o.will_run_tiled(g.cg, width, n_seed_rows)
+            from . import ops as _o                       # the f32 tile route is the only consumer of a folded table
+            f32 = all(l.fc_neigh.weight.dtype == torch.float32 for l in m.layers)
+            return f32 and _o.will_run_tiled(g.cg, width, n_seed_rows)
 
         def genes_partial(p_c):
             if torch.is_grad_enabled() and p_c.requires_grad:

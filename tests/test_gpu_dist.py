@@ -30,7 +30,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir, hidden, dropout, backend=BACKEND, force=False):
+def _worker(rank, world, port, out_dir, hidden, dropout, backend=BACKEND, force=False, n_layers=2):
     import torch.nn.functional as F
     import scdeepsort_amd as sda
     from oracle import wgnn_oracle as O
@@ -40,7 +40,8 @@ def _worker(rank, world, port, out_dir, hidden, dropout, backend=BACKEND, force=
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
     if backend == "nccl":
-        D.reserve_comm_cus()                                        # the production sequence: channel cap, then the communicator
+        D.reserve_comm_cus()                                        # default: no process-wide cap (opt-in since round 5)
+        D.reserve_comm_cus(cap_channels=True)                       # the opt-in sequence: channel cap, then the communicator
         assert os.environ["NCCL_MAX_NCHANNELS"] == str(D.COMM_CUS)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     else:
@@ -50,7 +51,7 @@ def _worker(rank, world, port, out_dir, hidden, dropout, backend=BACKEND, force=
         G, C, Din, ncls = 300, 1001, 40, 5                      # ragged shards (501 + 500)
         rp, col, val = S.synth_expression(C, G, 0.08, seed=3, device=dev)
         torch.manual_seed(0)                                     # identical parameters on both ranks
-        m = sda.GNN(Din, hidden, ncls, 2, G, activation=F.relu, dropout=dropout).to(dev)
+        m = sda.GNN(Din, hidden, ncls, n_layers, G, activation=F.relu, dropout=dropout).to(dev)
         with torch.no_grad():
             m.alpha.uniform_(0.5, 1.5)
         feats = S.synth_features(G + C, Din, device=dev)
@@ -62,7 +63,7 @@ def _worker(rank, world, port, out_dir, hidden, dropout, backend=BACKEND, force=
         # ---- inference: concat of both ranks' logits == the unsharded oracle on the whole graph
         sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
         expr = S.to_scipy(rp, col, val, G)
-        want = O.csr_forward(sd, O.build_csr_graph(expr), feats.cpu().numpy(), 2)
+        want = O.csr_forward(sd, O.build_csr_graph(expr), feats.cpu().numpy(), n_layers)
         m.eval()
         with torch.no_grad():
             got = eng.forward(feats[:G], feats[G + lo:G + hi])
@@ -78,7 +79,9 @@ def _worker(rank, world, port, out_dir, hidden, dropout, backend=BACKEND, force=
         with torch.no_grad():
             gsf = GraphedShardedForward(eng, feats[:G], feats[G + lo:G + hi])
             assert gsf.mode == ("whole" if backend == "nccl" else "segments"), gsf.mode
-            assert gsf.n_graphs == (1 if backend == "nccl" else 3) and gsf.n_eager_collectives == (0 if backend == "nccl" else 2)
+            # one [G, H] all-reduce per layer below the last + the logits concat
+            assert gsf.n_graphs == (1 if backend == "nccl" else n_layers + 1)
+            assert gsf.n_eager_collectives == (0 if backend == "nccl" else n_layers)
             for _ in range(2):
                 assert torch.equal(gsf(), got)
             f2 = feats * 0.5 + 0.01
@@ -86,6 +89,9 @@ def _worker(rank, world, port, out_dir, hidden, dropout, backend=BACKEND, force=
             assert torch.equal(gsf(f2[:G], f2[G + lo:G + hi]), want2) and not torch.equal(want2, got)
         graphed_mode = gsf.mode
         del gsf
+        if n_layers != 2:                                       # (the training checks below are written for two layers)
+            Path(out_dir, f"ok{rank}").write_text(json.dumps({"err": err, "backend": dist.get_backend(), "graphed": graphed_mode}))
+            return
         # ---- training step (cfg4): loss and ALL-REDUCED gradients == single-process autograd of the oracle
         labels = (torch.arange(C, device=dev) * 7 % ncls).long()
         opt = torch.optim.SGD(m.parameters(), lr=0.0)           # lr 0: inspect the gradients after the step
@@ -142,6 +148,15 @@ def _worker(rank, world, port, out_dir, hidden, dropout, backend=BACKEND, force=
 def test_world2_hip_sharded_engine_matches_unsharded_oracle(tmp_path, hidden, dropout):
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), hidden, dropout), nprocs=2, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(2))
+
+
+def test_world2_three_layer_segmented_replay_reduces_every_layer(tmp_path):
+    """the replayed collectives of a segmented capture must each target THEIR layer's partial sums.  With three
+    layers there are two [G, H] all-reduces; a thunk that closed over the loop variable would reduce the last layer's tensor
+    twice at replay and leave the first layer's partial sums unreduced (invisible with two layers: one all-reduce)."""
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), 32, 0.0, BACKEND, False, 3), nprocs=2, join=True)
+    recs = [json.loads(Path(tmp_path, f"ok{r}").read_text()) for r in range(2)]
+    assert all(r["graphed"] == "segments" and r["err"] < 1e-4 for r in recs)
 
 
 def test_world1_nccl_group_drives_the_sharded_branch(tmp_path):

@@ -2013,6 +2013,19 @@ def test_cross_entropy_sum_kernel_matches_torch(n, c):
     keep = torch.ones(n, dtype=torch.bool, device=DEV); keep[n // 2] = False; keep[0] = False
     if keep.any():
         np.testing.assert_allclose(xb.grad[keep].cpu().numpy(), 0.5 * x.grad[keep].cpu().numpy(), atol=2e-6)
+    # a label >= 2^32 must not alias a valid class; -100 is torch's ignore_index (loss 0, zero gradient row)
+    big = y.clone(); big[0] = (1 << 32) + 1
+    assert torch.isnan(ops.cross_entropy_sum(x.detach(), big)).item()
+    ign = y.clone(); ign[0] = -100
+    xi = x.detach().clone().requires_grad_(True)
+    li = ops.cross_entropy_sum(xi, ign)
+    li.backward()
+    xi64 = x.detach().double().requires_grad_(True)
+    ri = F.cross_entropy(xi64, ign, reduction="sum")
+    ri.backward()
+    assert abs(li.item() - ri.item()) < 2e-6 * max(1.0, abs(ri.item())) * max(1.0, n ** 0.5 / 30)
+    assert (xi.grad[0] == 0).all()
+    np.testing.assert_allclose(xi.grad.cpu().numpy(), xi64.grad.cpu().numpy(), atol=2e-6)
 
 
 @pytest.mark.parametrize("mode", ["cells", "genes", "plain"])

@@ -199,14 +199,17 @@ def test_cu_budget_of_the_pass_that_overlaps_a_collective():
     assert csr.tile_plan(32).n_tiles == one.n_tiles
     csr.cu_budget = 224                     # fits: a plan of its own (cached under its own key), within the budget
     assert csr.tile_plan(32).n_tiles <= 224 and len(csr._tile_plan) == 3
-    # the channel cap handed to RCCL matches the CUs left free; a value the user exported wins
+    # the channel cap handed to RCCL is OPT-IN (process-wide, calibrated on a stand-in); when asked for it matches the CUs
+    # left free; a value the user exported wins
     import os
     saved = os.environ.pop("NCCL_MAX_NCHANNELS", None)
     try:
         D.reserve_comm_cus()
+        assert "NCCL_MAX_NCHANNELS" not in os.environ
+        D.reserve_comm_cus(cap_channels=True)
         assert os.environ["NCCL_MAX_NCHANNELS"] == "32"
         os.environ["NCCL_MAX_NCHANNELS"] = "8"
-        D.reserve_comm_cus()
+        D.reserve_comm_cus(cap_channels=True)
         assert os.environ["NCCL_MAX_NCHANNELS"] == "8"
     finally:
         os.environ.pop("NCCL_MAX_NCHANNELS", None)
