@@ -3,7 +3,8 @@ source is not in the reference tree; the tree holds the equivalent CLI classes `
 and ``Runner`` (``predict.py:17-152``).  Same constructor keywords, same ``fit`` / ``predict`` signatures, same
 bundle on disk (``{species}-{tissue}.pt`` = ``{'model', 'optimizer'}`` (train.py:117-123), ``{tissue}_genes.txt`` /
 ``{tissue}_cell_type.txt`` written with ``\\r\\n`` (preprocess_internal.py:59-67), ``{species}_{tissue}_data.npz``
-support matrix (preprocess_internal.py:180)).
+support matrix (preprocess_internal.py:180)), read and written either as the reference's
+``pretrained/{species}/{models,graphs,statistics}/`` tree or as one flat directory (:class:`BundlePaths`).
 
 Only the per-cell hot path (graph normalisation, aggregation, autograd) runs on the GPU through the HIP
 kernels; file ingest, vocabularies and PCA are ordinary host code kept deliberately small.
@@ -123,6 +124,56 @@ def load_label_map(path, species: str) -> Tuple[dict, dict]:
     return old2new, old2sub
 
 
+class BundlePaths:
+    """Where the four files of a trained bundle live.  Two layouts:
+
+    * ``reference`` - the tree the reference's CLI writes and every released bundle ships as (``root`` = its ``pretrained``
+      directory): ``{root}/{species}/models/{species}-{tissue}.pt`` (train.py:20,117-123; predict.py:57),
+      ``{root}/{species}/graphs/{species}_{tissue}_data.npz`` (preprocess_internal.py:79,180; preprocess.py:114),
+      ``{root}/{species}/statistics/{tissue}_genes.txt`` / ``{tissue}_cell_type.txt`` (preprocess_internal.py:80,59-67;
+      preprocess.py:67-78).  ``root`` may also be the species directory itself (``pretrained/mouse``).
+    * ``flat`` - all four files in ``root`` (what ``fit(save_path=...)`` of the documented package example produces when it is
+      handed a plain directory, docs/api.rst:120-130).
+
+    ``layout="auto"``: reading picks the layout whose checkpoint exists (reference first); writing picks ``reference`` when
+    ``root`` is named ``pretrained`` or already holds a ``{species}/`` or ``models/`` subtree, else ``flat``."""
+
+    def __init__(self, root, species: str, tissue: str, layout: str = "auto", for_write: bool = False):
+        root = Path(root)
+        if layout not in ("auto", "flat", "reference"):
+            raise ValueError(f"bundle layout {layout!r}: auto, flat or reference")
+        ref_base = root if (root / "models").is_dir() and not (root / species).is_dir() else root / species
+        pt_name = f"{species}-{tissue}.pt"
+        if layout == "auto":
+            if for_write:
+                layout = "reference" if (root.name == "pretrained" or (root / species).is_dir() or (root / "models").is_dir()) else "flat"
+            else:
+                layout = "reference" if (ref_base / "models" / pt_name).exists() else "flat"
+        self.layout, self.root = layout, root
+        if layout == "reference":
+            self.model = ref_base / "models" / pt_name
+            self.support = ref_base / "graphs" / f"{species}_{tissue}_data.npz"
+            self.genes = ref_base / "statistics" / f"{tissue}_genes.txt"
+            self.cell_types = ref_base / "statistics" / f"{tissue}_cell_type.txt"
+            # the label map sits next to ``pretrained/`` in the reference tree (predict.py:125 reads ./map/ from the cwd)
+            self.map_candidates = [root / "celltype2subtype.xlsx", ref_base / "celltype2subtype.xlsx",
+                                   root.parent / "map" / "celltype2subtype.xlsx", ref_base.parent.parent / "map" / "celltype2subtype.xlsx",
+                                   Path("map") / "celltype2subtype.xlsx"]
+        else:
+            self.model = root / pt_name
+            self.support = root / f"{species}_{tissue}_data.npz"
+            self.genes = root / f"{tissue}_genes.txt"
+            self.cell_types = root / f"{tissue}_cell_type.txt"
+            self.map_candidates = [root / "celltype2subtype.xlsx", Path("map") / "celltype2subtype.xlsx"]
+
+    def mkdirs(self) -> None:
+        for f in (self.model, self.support, self.genes, self.cell_types):
+            f.parent.mkdir(parents=True, exist_ok=True)
+
+    def label_map(self) -> Optional[Path]:
+        return next((f for f in self.map_candidates if f.exists()), None)
+
+
 def _classify(logits: torch.Tensor, unsure_rate: float) -> Tuple[np.ndarray, np.ndarray]:
     """softmax -> 'unsure' iff max_prob < unsure_rate/num_classes, else argmax (predict.py:78-88)."""
     prob = F.softmax(logits.float(), dim=1)
@@ -143,6 +194,7 @@ class DeepSortClassifier:
         self.threshold, self.exclude_rate = threshold, exclude_rate
         self.random_seed, self.validation_fraction = random_seed, validation_fraction
         self.graph_steps = True                               # replay full-size mini-batch steps as one hipGraph each
+        self.bundle_layout = "auto"                           # "auto" | "flat" | "reference" (see BundlePaths)
         self.model: Optional[GNN] = None
         self.history: List[dict] = []
 
@@ -214,12 +266,12 @@ class DeepSortClassifier:
         # of ~10 per step)
         opt = torch.optim.Adam(model.parameters(), lr=self.learning_rate, weight_decay=self.weight_decay, capturable=will_graph,
                                fused=True)
-        save_path = Path(save_path) if save_path is not None else None
-        if save_path is not None:
-            save_path.mkdir(parents=True, exist_ok=True)
-            (save_path / f"{self.tissue}_genes.txt").write_bytes("".join(g + "\r\n" for g in id2gene).encode())
-            (save_path / f"{self.tissue}_cell_type.txt").write_bytes("".join(l + "\r\n" for l in id2label).encode())
-            sp.save_npz(save_path / f"{self.species}_{self.tissue}_data", expr)
+        bundle = BundlePaths(save_path, self.species, self.tissue, self.bundle_layout, for_write=True) if save_path is not None else None
+        if bundle is not None:
+            bundle.mkdirs()
+            bundle.genes.write_bytes("".join(g + "\r\n" for g in id2gene).encode())
+            bundle.cell_types.write_bytes("".join(l + "\r\n" for l in id2label).encode())
+            sp.save_npz(bundle.support, expr)
 
         def accuracy(ids):
             if len(ids) == 0:
@@ -253,9 +305,8 @@ class DeepSortClassifier:
             self.history.append(dict(epoch=epoch, loss=total / max(1, len(train_ids)), train_acc=tr_acc, val_acc=va_acc))
             if va_acc >= best:                                                # train.py:52-58
                 best = va_acc
-                if save_path is not None:
-                    torch.save({'model': model.state_dict(), 'optimizer': opt.state_dict()},
-                               save_path / f"{self.species}-{self.tissue}.pt")
+                if bundle is not None:
+                    torch.save({'model': model.state_dict(), 'optimizer': opt.state_dict()}, bundle.model)
             if tr_acc == 1:                                                   # train.py:62-63
                 break
         self.model, self._graph, self._feats, self._id2label, self._id2gene = model, graph, feats, id2label, id2gene
@@ -285,13 +336,18 @@ def _predict(species, tissue, input_file, model_path: Path, save_path, unsure_ra
                            gpu_id, threshold, seed)
 
 
-def _predict_on(species, tissue, input_file, model_path: Path, save_path, unsure_rate, file_type, dense_dim, hidden_dim,
-                gpu_id, threshold, seed) -> pd.DataFrame:
+def _predict_logits(species, tissue, input_file, model_path: Path, file_type, gpu_id, threshold, seed):
+    """The graph-side half of ``predict``: bundle -> predict graph (support cells + test cells) -> logits of the test cells.
+    Returns (logits [n_test, n_classes] on the device, test cell names, id2label, BundlePaths)."""
     dev = _device(gpu_id)
-    id2gene = [l.strip() for l in (model_path / f"{tissue}_genes.txt").read_text().splitlines() if l.strip()]
-    id2label = [l.strip() for l in (model_path / f"{tissue}_cell_type.txt").read_text().splitlines() if l.strip()]
-    support = sp.load_npz(model_path / f"{species}_{tissue}_data.npz").tocsr()           # preprocess.py:114-117
-    state = torch.load(model_path / f"{species}-{tissue}.pt", map_location=dev)['model']  # predict.py:56-59
+    bundle = BundlePaths(model_path, species, tissue)
+    missing = [str(f) for f in (bundle.model, bundle.support, bundle.genes, bundle.cell_types) if not f.exists()]
+    if missing:
+        raise FileNotFoundError(f"bundle for {species}/{tissue} under {model_path} ({bundle.layout} layout) lacks: " + ", ".join(missing))
+    id2gene = [l.strip() for l in bundle.genes.read_text().splitlines() if l.strip()]
+    id2label = [l.strip() for l in bundle.cell_types.read_text().splitlines() if l.strip()]
+    support = sp.load_npz(bundle.support).tocsr()                                        # preprocess.py:114-117
+    state = torch.load(bundle.model, map_location=dev)['model']                          # predict.py:56-59
     n_layers = sum(1 for k in state if k.endswith("fc_neigh.weight"))
     hidden_dim, dense_dim = state["layers.0.fc_neigh.weight"].shape
     G = len(id2gene)
@@ -312,13 +368,20 @@ def _predict_on(species, tissue, input_file, model_path: Path, save_path, unsure
     model.eval()
     seeds = range(G + n_sup, G + expr.shape[0])           # the test cells: one contiguous block of node ids (predict.py:64-76)
     with torch.no_grad():
-        pred, _ = _classify(model(graph, feats, seeds=seeds), unsure_rate)
+        logits = model(graph, feats, seeds=seeds)
+    return logits, df.index, id2label, bundle
+
+
+def _predict_on(species, tissue, input_file, model_path: Path, save_path, unsure_rate, file_type, dense_dim, hidden_dim,
+                gpu_id, threshold, seed) -> pd.DataFrame:
+    logits, index, id2label, bundle = _predict_logits(species, tissue, input_file, model_path, file_type, gpu_id, threshold, seed)
+    pred, _ = _classify(logits, unsure_rate)
     names = [id2label[p] if p >= 0 else "unsure" for p in pred]
-    out = pd.DataFrame({"index": df.index, "cell_type": names})
-    map_file = next((f for f in (model_path / "celltype2subtype.xlsx", Path("map") / "celltype2subtype.xlsx") if f.exists()), None)
+    out = pd.DataFrame({"index": index, "cell_type": names})
+    map_file = bundle.label_map()
     if map_file is not None:                                             # predict.py:124-146: new type / subtype names
         old2new, old2sub = load_label_map(map_file, species)
-        out = pd.DataFrame({"index": df.index, "cell_type": [old2new.get(p, p) for p in names],
+        out = pd.DataFrame({"index": index, "cell_type": [old2new.get(p, p) for p in names],
                             "cell_subtype": [old2sub.get(p, p) for p in names]})
     if save_path is not None:
         Path(save_path).mkdir(parents=True, exist_ok=True)

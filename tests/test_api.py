@@ -89,6 +89,12 @@ def test_fit_predict_roundtrip(tmp_path):
                            ["Mouse", "type1", "One", None]]})
     out3 = clf.predict(dt, model_path=tmp_path / "bundle")
     assert list(out3.columns) == ["index", "cell_type", "cell_subtype"]
+    # a save_path named `pretrained` is written as the reference's tree (train.py:20, preprocess_internal.py:79-80) and reloads
+    clf2 = sda.DeepSortClassifier("mouse", "Demo", dense_dim=16, hidden_dim=12, batch_size=64, n_epochs=2, n_layers=2, random_seed=1, gpu_id=0)
+    clf2.fit([(d1, c1)], save_path=tmp_path / "pretrained")
+    for rel in ("models/mouse-Demo.pt", "graphs/mouse_Demo_data.npz", "statistics/Demo_genes.txt", "statistics/Demo_cell_type.txt"):
+        assert (tmp_path / "pretrained" / "mouse" / rel).exists(), rel
+    assert len(clf2.predict(dt, model_path=tmp_path / "pretrained")) == 90
     want_t = {"type0": "Zero", "type1": "One"}; want_s = {"type0": "zero-a", "type1": "N/A"}
     assert out3["cell_type"].tolist() == [want_t.get(p, p) for p in out["cell_type"]]
     assert out3["cell_subtype"].tolist() == [want_s.get(p, p) for p in out["cell_type"]]
@@ -134,6 +140,85 @@ def test_fit_with_neighbour_subsampling(tmp_path):
     clf.fit([(d1, c1)])
     assert clf.num_neighbors == 8
     assert max(h["val_acc"] for h in clf.history) > 0.8
+
+
+def test_bundle_paths_resolve_both_layouts(tmp_path):
+    """f4: the reference's bundle tree (predict.py:57; preprocess.py:67-68,77-78,114; train.py:20; preprocess_internal.py:79-80)
+    and the flat directory; auto-detection for reading and for writing."""
+    from scdeepsort_amd.api import BundlePaths
+    root = tmp_path / "pretrained"
+    b = BundlePaths(root, "mouse", "Testis", for_write=True)                 # a directory NAMED pretrained: the reference tree
+    assert b.layout == "reference"
+    assert b.model == root / "mouse" / "models" / "mouse-Testis.pt"
+    assert b.support == root / "mouse" / "graphs" / "mouse_Testis_data.npz"
+    assert b.genes == root / "mouse" / "statistics" / "Testis_genes.txt"
+    assert b.cell_types == root / "mouse" / "statistics" / "Testis_cell_type.txt"
+    b.mkdirs()
+    assert (root / "mouse" / "models").is_dir() and (root / "mouse" / "graphs").is_dir() and (root / "mouse" / "statistics").is_dir()
+    flat = BundlePaths(tmp_path / "model_save_path", "mouse", "Testis", for_write=True)
+    assert flat.layout == "flat" and flat.model == tmp_path / "model_save_path" / "mouse-Testis.pt"
+    assert flat.genes == tmp_path / "model_save_path" / "Testis_genes.txt"
+    # reading: the layout whose checkpoint exists; the species directory itself is accepted as root
+    assert BundlePaths(root, "mouse", "Testis").layout == "flat"             # nothing written yet: falls back to flat
+    b.model.write_bytes(b"x")
+    assert BundlePaths(root, "mouse", "Testis").layout == "reference"
+    inner = BundlePaths(root / "mouse", "mouse", "Testis")
+    assert inner.layout == "reference" and inner.model == b.model and inner.genes == b.genes
+    assert BundlePaths(root, "mouse", "Testis", layout="flat").model == root / "mouse-Testis.pt"
+    # the label map of the reference tree sits next to pretrained/ (predict.py:125: ./map/celltype2subtype.xlsx)
+    (tmp_path / "map").mkdir()
+    (tmp_path / "map" / "celltype2subtype.xlsx").write_bytes(b"")
+    assert BundlePaths(root, "mouse", "Testis").label_map() == tmp_path / "map" / "celltype2subtype.xlsx"
+    with pytest.raises(ValueError):
+        BundlePaths(root, "mouse", "Testis", layout="tree")
+
+
+def _handwritten_bundle(tmp_path, layout):
+    """A bundle written BY HAND (no fit): parameters from the reference's own GNN.__init__ (tests/golden/refcode_predict.npz
+    `param.*`), the golden predict graph's support cells as graphs/*.npz, its test cells as the input csv."""
+    import scipy.sparse as sp
+    from pathlib import Path
+    from scdeepsort_amd.api import BundlePaths
+    z = np.load(Path(__file__).parent / "golden" / "refcode_predict.npz")
+    expr, mask = z["expr"].astype(np.float32), z["support_mask"].astype(bool)
+    genes = [f"Gene{i}" for i in range(expr.shape[1])]
+    labels = [f"type{i}" for i in range(int(z["n_classes"]))]
+    root = tmp_path / ("pretrained" if layout == "reference" else "flatdir")
+    b = BundlePaths(root, "mouse", "Demo", layout=layout, for_write=True)
+    b.mkdirs()
+    b.genes.write_bytes("".join(g + "\r\n" for g in genes).encode())
+    b.cell_types.write_bytes("".join(l + "\r\n" for l in labels).encode())
+    sp.save_npz(b.support, sp.csr_matrix(expr[mask]))
+    state = {k[len("param."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param.")}
+    torch.save({"model": state, "optimizer": {}}, b.model)
+    test = expr[~mask]
+    cells = [f"T{j}" for j in range(test.shape[0])]
+    data = tmp_path / f"mouse_Demo_test_{layout}.csv"
+    pd.DataFrame(test.T, index=genes, columns=cells).to_csv(data)
+    return root, data, cells
+
+
+@pytest.mark.gpu
+def test_reference_layout_bundle_loads_as_shipped(tmp_path):
+    """a bundle in the reference's `pretrained/{species}/{models,graphs,statistics}/` layout - written by
+    hand, parameters from the reference's own constructor - loads and gives the same logits as the flat bundle."""
+    from scdeepsort_amd.api import _predict_logits
+    root_r, data_r, cells = _handwritten_bundle(tmp_path, "reference")
+    root_f, data_f, _ = _handwritten_bundle(tmp_path, "flat")
+    assert (root_r / "mouse" / "models" / "mouse-Demo.pt").exists() and (root_f / "mouse-Demo.pt").exists()
+    lr, idx, labels, br = _predict_logits("mouse", "Demo", data_r, root_r, "csv", 0, 0, 10086)
+    lf, _, _, bf = _predict_logits("mouse", "Demo", data_f, root_f, "csv", 0, 0, 10086)
+    assert br.layout == "reference" and bf.layout == "flat"
+    assert lr.shape == (len(cells), 4) and list(idx) == cells and labels == [f"type{i}" for i in range(4)]
+    assert torch.equal(lr, lf) and torch.isfinite(lr).all()
+    out_r = sda.DeepSortPredictor("mouse", "Demo", unsure_rate=0.).predict(data_r, model_path=root_r)
+    out_f = sda.DeepSortPredictor("mouse", "Demo", unsure_rate=0.).predict(data_f, model_path=root_f)
+    assert out_r["cell_type"].tolist() == out_f["cell_type"].tolist() == [labels[i] for i in lr.argmax(1).tolist()]
+    # the species directory as model_path, and a fit() that is told to write the reference tree
+    out_s = sda.DeepSortPredictor("mouse", "Demo", unsure_rate=0.).predict(data_r, model_path=root_r / "mouse")
+    assert out_s["cell_type"].tolist() == out_r["cell_type"].tolist()
+    with pytest.raises(FileNotFoundError):
+        sda.DeepSortPredictor("mouse", "Nope").predict(data_r, model_path=root_r)
 
 
 def _write_xlsx(path, sheets):
