@@ -108,6 +108,86 @@ def cpu_baseline(graph, model, feats_g, feats_c, gpu_logits, cfg):
             "all": every}
 
 
+def workload_string(cfg, total_cells, mode):
+    """`config.workload` of the line.  A pure function of the config and the scaling mode - NOT of the number of ranks - so that
+    the N = 1 leg of a SCALE run names the same workload as the BENCH line (tests/test_host_logic.py pins it)."""
+    return (f"{cfg.name}: {total_cells} cells x {cfg.genes} genes"
+            f"{' (ONE job, cells sharded over the ranks)' if mode == 'strong' else ' in total (' + str(cfg.cells) + ' per GPU)'}, "
+            f"density {cfg.density}, dense_dim {cfg.dense_dim}, hidden {cfg.hidden}, "
+            f"{cfg.n_layers}-layer WGNN forward + {cfg.n_classes}-class head")
+
+
+def device_identity(dev):
+    """Hardware identity of this rank's device, so that a multi-rank record can be read for "did the N ranks sit on N
+    devices": PCI domain:bus:device and UUID from the runtime's device properties (rocm-smi as a fallback for the bus id)."""
+    p = torch.cuda.get_device_properties(dev)
+    ident = {"name": p.name, "arch": getattr(p, "gcnArchName", None), "cus": p.multi_processor_count}
+    try:
+        ident["pci"] = f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}"
+    except Exception:
+        ident["pci"] = None
+    try:
+        ident["uuid"] = str(p.uuid)
+    except Exception:
+        ident["uuid"] = None
+    if ident["pci"] is None and ident["uuid"] is None:
+        try:
+            import subprocess
+            out = subprocess.run(["rocm-smi", "--showbus"], capture_output=True, text=True, timeout=20).stdout
+            ident["rocm_smi_showbus"] = [l.strip() for l in out.splitlines() if "PCI Bus" in l][: torch.cuda.device_count()]
+        except Exception:
+            pass
+    return ident
+
+
+def one_shot_costs(cfg, model, dev, S, sda, steady_ms):
+    """Secondary (never `value`): what ONE inference on a NEW graph costs - the reference's inference is one forward per built
+    graph (predict.py:44-54,61-88), while `value` times the steady-state forward on a resident graph.  Every figure is wall
+    time around device work with a synchronize on both sides, on operands generated outside the timed regions:
+      graph_build_ms  : K4 normalisation of both directions + the gene-major transpose (CellGeneGraph.from_device_csr)
+      plan_build_ms   : the tile plans of both directions at the forward's width
+      first_forward_ms: the first forward on the new graph (plans already built; allocator warm)
+      predict_end_to_end_ms: DeepSortPredictor-shaped - 10 000 support cells + 100 000 test cells x the config's genes
+                        (test cells feed no genes, preprocess.py:184-187): build + plans + ONE forward of the test cells"""
+    from scdeepsort_amd import ops
+    from scdeepsort_amd.graph import CellGeneGraph
+    G = cfg.genes
+
+    def wall(fn):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); r = fn(); torch.cuda.synchronize()
+        return (time.perf_counter() - t0) * 1e3, r
+    kb = ops.tiled_block_rows(-(-min(cfg.hidden, 256) // 4) * 4)
+    rp, col, val = S.synth_expression(cfg.cells, G, cfg.density, seed=S.REFERENCE_SEED + 17, device=dev)
+    feats = S.synth_features(G + cfg.cells, cfg.dense_dim, seed=23, device=dev, dtype=cfg.feature_dtype)
+    t_graph, g = wall(lambda: CellGeneGraph.from_device_csr(rp, col, val, G))
+    t_plan, _ = wall(lambda: (g.cg.tile_plan(kb), g.gc.tile_plan(kb)) if ops.tiled_kernel_serves(g.cg, cfg.hidden) else None)
+    with torch.no_grad():
+        t_first, _ = wall(lambda: model(g, feats))
+        t_second, _ = wall(lambda: model(g, feats))
+    rec = {"graph_build_ms": round(t_graph, 2), "plan_build_ms": round(t_plan, 2), "first_forward_ms": round(t_first, 2),
+           "second_forward_ms": round(t_second, 2),
+           "forwards_that_amortise_the_plans": round(t_plan / max(steady_ms, 1e-6), 1),
+           "graph": f"{cfg.cells} cells x {G} genes, a NEW graph (seed + 17)"}
+    del g, rp, col, val, feats
+    if not cfg.total_cells and cfg.cells >= 50_000:
+        n_sup, n_test = 10_000, cfg.cells
+        rp, col, val = S.synth_expression(n_sup + n_test, G, cfg.density, seed=S.REFERENCE_SEED + 29, device=dev)
+        feats = S.synth_features(G + n_sup + n_test, cfg.dense_dim, seed=31, device=dev, dtype=cfg.feature_dtype)
+        mask = torch.zeros(n_sup + n_test, dtype=torch.bool, device=dev); mask[:n_sup] = True
+        seeds = range(G + n_sup, G + n_sup + n_test)
+
+        def predict():
+            gp = CellGeneGraph.from_device_csr(rp, col, val, G, support_mask=mask)
+            with torch.no_grad():
+                return model(gp, feats, seeds=seeds)
+        t_e2e, out = wall(predict)
+        assert out.shape[0] == n_test and torch.isfinite(out).all()
+        rec["predict_end_to_end_ms"] = round(t_e2e, 2)
+        rec["predict_graph"] = (f"{n_sup} support + {n_test} test cells x {G} genes, {cfg.n_layers} layers: graph build + tile plans + ONE "
+                                "forward of the test cells (api._predict_logits' device side; CSV ingest and PCA are host work outside it)")
+    return rec
+
+
 def self_launch(args):
     """``python bench.py --gpus N`` (N > 1) outside a launcher: start N ranks of this script under
     torch.distributed.run, one per GPU.  A box with fewer than N GPUs fails loudly - unless WGNN_BENCH_SHARE_GPU=1
@@ -223,7 +303,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             from scdeepsort_amd import dist as wdist
-            wdist.reserve_comm_cus()                     # the communicator's channels = the CUs the tile geometry leaves free
+            wdist.reserve_comm_cus()                     # (the RCCL channel cap is opt-in: WGNN_CAP_NCCL_CHANNELS=1, see dist.py)
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
@@ -252,6 +332,8 @@ def main():
     mode = args.scaling
     t_setup = time.time()
     (rp, col, val), feats_g, feats_c, total_cells, whole = build_workload(cfg, mode, rank, world, dev, S, sda.dist.shard_range)
+    torch.cuda.synchronize()
+    t_generate = time.time() - t_setup
     C = feats_c.shape[0]                             # cells held by THIS rank
     torch.manual_seed(1234)
     model = sda.GNN(cfg.dense_dim, cfg.hidden, cfg.n_classes, cfg.n_layers, G, activation=F.relu)
@@ -262,6 +344,16 @@ def main():
     del rp, col, val
     torch.cuda.synchronize()
     t_setup = time.time() - t_setup
+
+    # ---- N > 1: which device does every rank drive?  (a SCALE record must show that RCCL saw N devices)
+    ident = device_identity(dev)
+    if world > 1:
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        keys = [i.get("uuid") or i.get("pci") for i in idents]
+        if not share and all(k is not None for k in keys) and len(set(keys)) != world:
+            sys.exit(f"bench.py: {world} ranks but only {len(set(keys))} distinct device(s): {keys} "
+                     "(WGNN_BENCH_SHARE_GPU=1 is the debug mode that shares one)")
 
     # launch-bound configs (cfg2: ~25 launches of a few us each): the same forward captured once and replayed as one hipGraph
     # launch per step (scdeepsort_amd.graphed.GraphedForward); per-launch HIP events cannot be recorded inside a replay, so
@@ -302,6 +394,21 @@ def main():
                 launch_desc = f"eager (measured faster than the captured graph: {launch_calibration} ms per step)"
             else:
                 launch_desc += f" (measured faster than eager: {launch_calibration} ms per step)"
+    # ---- N > 1: the tile geometry of the pass that overlaps the [G, H] all-reduce - planned for 256 - WGNN_COMM_CUS CUs (default
+    # 32, calibrated on a spin-kernel stand-in: profiles/r04_comm_contention.json) or for the whole chip?  Both are timed next to
+    # the REAL communicator, every rank keeps the job-wide faster one (max over ranks), both are reported.
+    comm_cus_calibration = None
+    if world > 1 and not graphed and engine.overlap_cu_budget != 256 and os.environ.get("WGNN_BENCH_COMM_AB", "1") == "1":
+        n_cal = max(3, min(10, args.steps))
+        budgets = {"reserved": engine.overlap_cu_budget, "full_chip": 256}
+        cal = {}
+        for name, bud in budgets.items():
+            engine.overlap_cu_budget = bud
+            cal[name] = timed_steps(engine, feats_g, feats_c, n_cal, 2, world, dev, profile=False)[0] / n_cal * 1e3
+        keep = min(cal, key=cal.get)
+        engine.overlap_cu_budget = budgets[keep]
+        comm_cus_calibration = {"ms_per_step": {k: round(v, 4) for k, v in cal.items()}, "kept": keep,
+                                "cus_planned_for_the_overlapped_pass": budgets[keep], "WGNN_COMM_CUS": sda.dist.COMM_CUS}
     dt, dt_local, prof, out = timed_steps(engine, feats_g, feats_c, args.steps, args.warmup, world, dev, step=step_fn)
     assert torch.isfinite(out).all()
     eager_ms = None
@@ -389,7 +496,8 @@ def main():
     # ---- N > 1: every rank's own dominant-kernel roofline (HIP events on that rank's stream) + the communicator's view
     per_gpu, comm = None, None
     if world > 1:
-        mine = {"rank": rank, "device": f"cuda:{local_rank}", "gpu": torch.cuda.get_device_name(dev), "cells": C,
+        mine = {"rank": rank, "device": f"cuda:{local_rank}", "gpu": torch.cuda.get_device_name(dev), "pci": ident.get("pci"),
+                "uuid": ident.get("uuid"), "cells": C,
                 "nnz": engine.nnz, "kernel": dom["kernel"], "avg_launch_ms": dom["avg_ms"],
                 "achieved_GBs": dom["achieved_GBs"], "frac": round(dom["achieved_GBs"] / HBM_PEAK_GBS, 4),
                 "forward_alg_bytes": fwd_bytes, "forward_achieved_GBs": roofline["forward_achieved_GBs"],
@@ -400,7 +508,9 @@ def main():
         per_gpu = [None] * world
         dist.all_gather_object(per_gpu, mine)
         comm = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "shared_device": share,
-                "cus_left_to_the_communicator": sda.dist.COMM_CUS, "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"),
+                "distinct_devices": len({p.get("uuid") or p.get("pci") or p["device"] for p in per_gpu}),
+                "cus_left_to_the_communicator": 256 - engine.overlap_cu_budget, "comm_cus_calibration": comm_cus_calibration,
+                "NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"),
                 "collectives_per_step": "1 all-reduce [G,H] (genes<-cells partial sums) + 1 all-gather of the logits"}
         roofline["per_gpu"] = per_gpu
         roofline["aggregate_peak_GBs"] = HBM_PEAK_GBS * (1 if share else world)
@@ -453,6 +563,12 @@ def main():
                               "(K2t on pre-scaled rows, wgnn_agg_bwd_prepare, matrix-core weight gradients) + fused Adam"}
         del tm, topt, tf
 
+    # ---- secondary (never `value`): the one-shot path - graph build, plan build, first forward, predictor-shaped end to end
+    one_shot = None
+    if world == 1 and not args.no_secondary and os.environ.get("WGNN_BENCH_ONE_SHOT", "1") == "1":
+        one_shot = one_shot_costs(cfg, model, dev, S, sda, ms_per_step)
+        one_shot["bench_workload_generate_s"] = round(t_generate, 2)
+
     # ---- CPU baseline: the restatement (C/OpenMP aggregation + torch Linear) on this host, rank 0, N = 1 only
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -463,16 +579,14 @@ def main():
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
                 "higher_is_better": True, "scaling": mode, "vs_baseline": None,
                 "dtype": "f32" if cfg.feature_dtype == torch.float32 else "f32 (fp16-stored input features)", "data": "synthetic",
-                "config": {"workload": f"{cfg.name}: {total_cells} cells x {G} genes"
-                                       f"{' (ONE job, cells sharded over the ranks)' if mode == 'strong' else ' in total (' + str(cfg.cells) + ' per GPU)'}, "
-                                       f"density {cfg.density}, dense_dim {cfg.dense_dim}, hidden {cfg.hidden}, "
-                                       f"{cfg.n_layers}-layer WGNN forward + {cfg.n_classes}-class head",
+                "config": {"workload": workload_string(cfg, total_cells, mode),
                            "cells_total": total_cells, "cells_this_rank": C,
                            "nnz_per_gpu": per_gpu[0]["nnz"] if per_gpu else roofline["passes"][0]["nnz"],
-                           "parallelism": f"cell-shard x{world}", "setup_s": round(t_setup, 1), "communicator": comm,
+                           "parallelism": f"cell-shard x{world}", "setup_s": round(t_setup, 1), "device": ident, "communicator": comm,
                            "gemm_selection": gemm_selection, "step_launch": launch_desc, "eager_ms_per_step": eager_ms, "launch_calibration_ms": launch_calibration,
                            "sharded_vs_unsharded": self_check},
-                "roofline": roofline, "cpu_baseline": cpu, "sustained": sustained, "weak_scaling": weak, "train_step": train_step}
+                "roofline": roofline, "cpu_baseline": cpu, "sustained": sustained, "weak_scaling": weak, "train_step": train_step,
+                "one_shot": one_shot}
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

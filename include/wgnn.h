@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define WGNN_VERSION 203           /* 0.2.x - INCOMPATIBLE with 0.1.x binders: `neigh_sum` was inserted before `n_out` in
+#define WGNN_VERSION 204           /* 0.2.x - INCOMPATIBLE with 0.1.x binders: `neigh_sum` was inserted before `n_out` in
                                       wgnn_agg_fwd / wgnn_agg_fwd_tiled (0.1.1, should have been a major bump then - a 0.1.0
                                       caller would pass n_out in a pointer slot); 0.2.0 adds int64 row pointers
                                       (WGNN_FLAG_ROWPTR_I64, wgnn_normalize_rows_i64), WGNN_FLAG_SRC_PRESCALED and
@@ -51,7 +51,14 @@ extern "C" {
                                       library would misread the marks, so a plan that carries them needs >= 201.
                                       0.2.2: WGNN_FLAG_OUT_SCALE_ALPHA (an older library ignores the bit: callers that set it
                                       need >= 202).  0.2.3: wgnn_agg_bwd_prepare, wgnn_ce_sum_fwd_bwd; wgnn_agg_bwd_src_tiled
-                                      takes col_scale == NULL (pre-scaled gradient rows). */
+                                      takes col_scale == NULL (pre-scaled gradient rows).  0.2.4: WGNN_PLAN_TALL (tall tile
+                                      plans: 8 waves x 49 rows). */
+
+/* Tile-plan geometry, OR-ed into the `block_rows` argument of wgnn_agg_fwd_tiled / wgnn_agg_bwd_src_tiled /
+ * wgnn_agg_bwd_alpha_tiled (0.2.4; an older library rejects the bit with WGNN_ERR_PLAN): the plan was built for the TALL tile -
+ * 8 waves x 49 destination rows = 392 item slots per tile, seg_ptr with 8 segments per (tile, block), 6-bit slot fields in the
+ * entries - instead of 16 waves x 16 rows = 256 item slots, 16 segments, 4-bit slots. */
+#define WGNN_PLAN_TALL (1 << 16)
 
 /* error codes */
 #define WGNN_OK                 0

@@ -32,7 +32,10 @@ def needs_build() -> bool:
 
 
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-pass-failed", "-Wno-inline-asm", f"-I{ROOT / 'include'}"]
-HAND_VGPRS = range(32, 128)         # csrc/gen_flat_asm.py HAND_VGPR_FIRST .. HAND_VGPR_LAST
+HAND_VGPRS = range(32, 128)         # agg_tiled_flat4: hand-owned registers (csrc/gen_flat_asm.py MAPS["flat"])
+TALL_STATE_VGPRS = range(42, 256)   # agg_tiled_tall: registers that carry state ACROSS asm statements (segment / chunk registers,
+                                    # accumulators); v20..v41 are statement-local there and shared with the compiler
+KERNELS = {"agg_tiled_flat4": dict(hand=HAND_VGPRS, vgprs=128), "agg_tiled_tall": dict(hand=TALL_STATE_VGPRS, vgprs=256)}
 
 
 class RegisterContractError(RuntimeError):
@@ -59,7 +62,7 @@ def flat4_resource_usage() -> dict:
     for line in r.stderr.splitlines():                       # remark blocks: "Function Name: <sym>" then one remark per figure
         m = re.search(r"remark: +(?:Function )?Name: (\S+)", line)
         if m:
-            cur = kernels.setdefault(m.group(1), {"remarks": {}}) if "agg_tiled_flat4" in m.group(1) else None
+            cur = kernels.setdefault(m.group(1), {"remarks": {}}) if any(k in m.group(1) for k in KERNELS) else None
             continue
         m = re.search(r"remark: +([A-Za-z ]+?)(?: \[[^\]]*\])?: (\S+)", line)
         if m and cur is not None:
@@ -77,6 +80,8 @@ def flat4_resource_usage() -> dict:
         body_start = asm.index(f"\n{name}:")
         body = asm[body_start: asm.index(".Lfunc_end", body_start)]
         bad, in_asm = [], False
+        hand = next(v["hand"] for k, v in KERNELS.items() if k in name)
+        rec["want_vgprs"] = next(v["vgprs"] for k, v in KERNELS.items() if k in name)
         for ln in body.splitlines():
             t = ln.strip()
             if t.startswith(";;#ASMSTART"):
@@ -87,7 +92,7 @@ def flat4_resource_usage() -> dict:
                 code = t.split(";")[0]
                 regs = [("v", int(a), int(b or a)) for a, b in re.findall(r"\bv\[?(\d+)(?::(\d+))?\]?", code)]
                 for kind, lo, hi in regs:
-                    if hi >= HAND_VGPRS.start and lo < HAND_VGPRS.stop:
+                    if hi >= hand.start and lo < hand.stop:
                         # reads of chunk / segment / accumulator registers that the SOURCE asks for are inside asm
                         # statements; anything here was emitted by the compiler on its own
                         bad.append(code)
@@ -101,8 +106,9 @@ def audit_flat4(usage: dict | None = None) -> dict:
     any instantiation spills, uses scratch, does not get exactly 128 VGPRs, or when the compiler itself touches a
     hand-owned register."""
     usage = flat4_resource_usage() if usage is None else usage
-    if len(usage) < 6:
-        raise RegisterContractError(f"expected 6 agg_tiled_flat4 instantiations, found {sorted(usage)}")
+    for k in KERNELS:
+        if sum(k in name for name in usage) < 6:
+            raise RegisterContractError(f"expected 6 {k} instantiations, found {sorted(usage)}")
     for name, rec in usage.items():
         md, rm = rec["metadata"], rec["remarks"]
         problems = []
@@ -110,10 +116,11 @@ def audit_flat4(usage: dict | None = None) -> dict:
             problems.append(f"spills: {md}")
         if md.get("private_segment_fixed_size", -1) != 0:
             problems.append(f"scratch: {md}")
-        if md.get("vgpr_count") != 128:
-            problems.append(f"vgpr_count {md.get('vgpr_count')} != 128 (4 waves per SIMD)")
+        want = rec.get("want_vgprs", 128)
+        if md.get("vgpr_count") != want:
+            problems.append(f"vgpr_count {md.get('vgpr_count')} != {want} ({512 // want} waves per SIMD)")
         if rm.get("SGPRs Spill") != "0" or rm.get("VGPRs Spill") != "0" or rm.get("ScratchSize") not in ("0", None) or \
-                rm.get("VGPRs") != "128":
+                rm.get("VGPRs") != str(want):
             problems.append(f"resource remarks: {rm}")
         if rec["compiler_touches_hand_registers"]:
             problems.append("compiler-emitted instructions name hand-owned registers: "

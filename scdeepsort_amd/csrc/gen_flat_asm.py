@@ -41,17 +41,25 @@ import os
 import sys
 
 N_PAIRS = 32
-# the hand-owned part of the register file (the compiler gets v[0:31] / s[0:79]: amdgpu_num_vgpr / amdgpu_num_sgpr)
-HAND_VGPR_FIRST, HAND_VGPR_LAST = 32, 127
+# Register maps (round 5: two tile geometries share this pipeline).
+#   flat: 16 waves x 128 VGPRs, 16 destination rows per wave.  The compiler gets v[0:31]; v[32:127] are hand-owned.
+#   tall: 8 waves x 256 VGPRs, 49 destination rows per wave.  The compiler gets v[0:41]; the staging / weight / address
+#         registers v[20:41] are STATEMENT-LOCAL (dead between asm statements, named as clobbers: the compiler may use them
+#         between statements and in the epilogue, never across one); v[42:255] carry state across statements (segment /
+#         entry-chunk registers v[42:59], accumulators v[60:255]) and lie beyond the compiler's cap.
+MAPS = {
+    "flat": dict(macro="WGNN_FLAT4_ASM", acc=64, x=[(48, 52), (56, 60), (96, 100)], w=[40, 42, 104], a0=44, a1=45,
+                 hand=(32, 127), clob="WGNN_HAND_VGPRS", label="w4"),
+    "tall": dict(macro="WGNN_TALL_ASM", acc=60, x=[(20, 24), (28, 32)], w=[36, 38], a0=40, a1=41,
+                 hand=(20, 255), clob="WGNN_TALL_VGPRS", label="w8"),
+}
+M = MAPS["flat"]
+HAND_VGPR_FIRST, HAND_VGPR_LAST = MAPS["flat"]["hand"]
 HAND_SGPR_FIRST, HAND_SGPR_LAST = 80, 95
 ABLATE = set(filter(None, os.environ.get("WGNN_GEN_ABLATE", "").split(",")))   # timing experiments only (wrong results)
 DEPTH = int(os.environ.get("WGNN_GEN_DEPTH", "1"))      # LDS reads are issued DEPTH steps ahead of their FMAs
-XREGS = [(48, 52), (56, 60), (96, 100)]    # staging buffers, first regs of entry 0 / entry 1 (third: DEPTH=2 experiment)
-WREGS = [40, 42, 104]
-
-
 def xreg(p):
-    return XREGS[p % (DEPTH + 1)]
+    return M["x"][p % (DEPTH + 1)]    # staging buffers, first regs of entry 0 / entry 1 (flat's third: DEPTH=2 experiment)
 
 
 def sset(p):
@@ -60,7 +68,17 @@ def sset(p):
 
 
 def wreg(p):
-    return WREGS[p % (DEPTH + 1)]
+    return M["w"][p % (DEPTH + 1)]
+
+
+def acc(k):
+    """Accumulator operand of slot 0 (the GPR index adds 4 * slot): registers acc + k, acc + k + 1."""
+    return f"v[{M['acc'] + k}:{M['acc'] + k + 1}]"
+
+
+def L(name):
+    """Label with the map's prefix (both pipelines may be instantiated in one translation unit)."""
+    return name.replace("Lw4_", f"L{M['label']}_")
 
 
 FMA2 = "fma2" in ABLATE          # v_fma_f32 x4 instead of v_pk_fma_f32 x2 per entry (a REAL variant: results stay correct)
@@ -74,6 +92,8 @@ NORL = "norl" in ABLATE          # timing only: no per-pair v_readlane (every en
 NOWT = "nowt" in ABLATE          # timing only: no ds_read_b64 of the pair's weights (stale weight registers)
 HALF = "halfmodel" in ABLATE     # timing only (D <= 128): the cost structure of a half-wave pipeline - the two entries of a pair share ONE
                                  # ds_read_b128 (lanes 0-31 one source row, lanes 32-63 the other) and one pair of packed FMAs
+IDXMODE = "idxmode" in ABLATE    # a REAL variant (results stay correct): GPR-index mode is switched on ONCE per chunk; a step only moves
+                                 # the index (s_set_gpr_idx_idx) and parks it at 0 behind its FMAs - no MODE-register write per step
 SMEM = "smem" in ABLATE          # timing only, with norl,nowt: the cost side of a scalar-cache entry feed - every 4th pair step drains
                                  # lgkmcnt (SMEM returns out of order: only 0 proves a scalar load landed) and issues one
                                  # s_load_dwordx16 (8 entries = 4 pairs) from the chunk's own address (operand %[ep], clobbers s[64:79])
@@ -109,8 +129,8 @@ def addresses(p):
     s = sset(p)
     if "noaddr" in ABLATE:
         return []
-    return [f"v_and_or_b32 v44, s{s['pk0']}, %[mk], %[lb]",
-            f"v_and_or_b32 v45, s{s['pk1']}, %[mk], %[lb]"]
+    return [f"v_and_or_b32 v{M['a0']}, s{s['pk0']}, %[mk], %[lb]",
+            f"v_and_or_b32 v{M['a1']}, s{s['pk1']}, %[mk], %[lb]"]
 
 
 def reads(p):
@@ -119,11 +139,11 @@ def reads(p):
         return []
     w = wreg(p)
     if WRL:
-        return [f"ds_read_b128 v[{x0}:{x0 + 3}], v44", f"ds_read_b128 v[{x1}:{x1 + 3}], v45"] + wreadlanes(p)
+        return [f"ds_read_b128 v[{x0}:{x0 + 3}], v{M['a0']}", f"ds_read_b128 v[{x1}:{x1 + 3}], v{M['a1']}"] + wreadlanes(p)
     if HALF:
-        return [f"ds_read_b128 v[{x0}:{x0 + 3}], v44", f"ds_read_b64 v[{w}:{w + 1}], %[wb] offset:{8 * p}"]
-    return [f"ds_read_b128 v[{x0}:{x0 + 3}], v44",
-            f"ds_read_b128 v[{x1}:{x1 + 3}], v45"] + ([] if NOWT else [f"ds_read_b64 v[{w}:{w + 1}], %[wb] offset:{8 * p}"])
+        return [f"ds_read_b128 v[{x0}:{x0 + 3}], v{M['a0']}", f"ds_read_b64 v[{w}:{w + 1}], %[wb] offset:{8 * p}"]
+    return [f"ds_read_b128 v[{x0}:{x0 + 3}], v{M['a0']}",
+            f"ds_read_b128 v[{x1}:{x1 + 3}], v{M['a1']}"] + ([] if NOWT else [f"ds_read_b64 v[{w}:{w + 1}], %[wb] offset:{8 * p}"])
 
 
 def fmas(p):
@@ -136,31 +156,31 @@ def fmas(p):
     if FMA2:       # experiment: four v_fma_f32 per entry instead of two v_pk_fma_f32 (same arithmetic, same registers)
         w0, w1 = wreg(p), wreg(p) + 1
         return [f"s_set_gpr_idx_on s{s['pk0']}, gpr_idx(SRC2,DST)"] + \
-               [f"v_fma_f32 v{64 + k}, v{w0}, v{x0 + k}, v{64 + k}" for k in range(4)] + \
+               [f"v_fma_f32 v{M['acc'] + k}, v{w0}, v{x0 + k}, v{M['acc'] + k}" for k in range(4)] + \
                [f"s_set_gpr_idx_idx s{s['pk1']}"] + \
-               [f"v_fma_f32 v{64 + k}, v{w1}, v{x1 + k}, v{64 + k}" for k in range(4)] + \
+               [f"v_fma_f32 v{M['acc'] + k}, v{w1}, v{x1 + k}, v{M['acc'] + k}" for k in range(4)] + \
                ["s_set_gpr_idx_off"]
     if WRL:
         w0, w1 = wsgpr(p)
         return [f"s_set_gpr_idx_on s{s['pk0']}, gpr_idx(SRC2,DST)",
-                f"v_pk_fma_f32 v[64:65], s[{w0}:{w0 + 1}], v[{x0}:{x0 + 1}], v[64:65] {lo}",
-                f"v_pk_fma_f32 v[66:67], s[{w0}:{w0 + 1}], v[{x0 + 2}:{x0 + 3}], v[66:67] {lo}",
+                f"v_pk_fma_f32 {acc(0)}, s[{w0}:{w0 + 1}], v[{x0}:{x0 + 1}], {acc(0)} {lo}",
+                f"v_pk_fma_f32 {acc(2)}, s[{w0}:{w0 + 1}], v[{x0 + 2}:{x0 + 3}], {acc(2)} {lo}",
                 f"s_set_gpr_idx_idx s{s['pk1']}",
-                f"v_pk_fma_f32 v[64:65], s[{w1}:{w1 + 1}], v[{x1}:{x1 + 1}], v[64:65] {lo}",
-                f"v_pk_fma_f32 v[66:67], s[{w1}:{w1 + 1}], v[{x1 + 2}:{x1 + 3}], v[66:67] {lo}",
+                f"v_pk_fma_f32 {acc(0)}, s[{w1}:{w1 + 1}], v[{x1}:{x1 + 1}], {acc(0)} {lo}",
+                f"v_pk_fma_f32 {acc(2)}, s[{w1}:{w1 + 1}], v[{x1 + 2}:{x1 + 3}], {acc(2)} {lo}",
                 "s_set_gpr_idx_off"]
     if HALF:
         return [f"s_set_gpr_idx_on s{s['pk0']}, gpr_idx(SRC2,DST)",
-                f"v_pk_fma_f32 v[64:65], {w}, v[{x0}:{x0 + 1}], v[64:65] {lo}",
-                f"v_pk_fma_f32 v[66:67], {w}, v[{x0 + 2}:{x0 + 3}], v[66:67] {lo}",
+                f"v_pk_fma_f32 {acc(0)}, {w}, v[{x0}:{x0 + 1}], {acc(0)} {lo}",
+                f"v_pk_fma_f32 {acc(2)}, {w}, v[{x0 + 2}:{x0 + 3}], {acc(2)} {lo}",
                 "s_set_gpr_idx_off"]
-    return [f"s_set_gpr_idx_on s{s['pk0']}, gpr_idx(SRC2,DST)",
-            f"v_pk_fma_f32 v[64:65], {w}, v[{x0}:{x0 + 1}], v[64:65] {lo}",
-            f"v_pk_fma_f32 v[66:67], {w}, v[{x0 + 2}:{x0 + 3}], v[66:67] {lo}",
+    return [f"s_set_gpr_idx_idx s{s['pk0']}" if IDXMODE else f"s_set_gpr_idx_on s{s['pk0']}, gpr_idx(SRC2,DST)",
+            f"v_pk_fma_f32 {acc(0)}, {w}, v[{x0}:{x0 + 1}], {acc(0)} {lo}",
+            f"v_pk_fma_f32 {acc(2)}, {w}, v[{x0 + 2}:{x0 + 3}], {acc(2)} {lo}",
             f"s_set_gpr_idx_idx s{s['pk1']}",
-            f"v_pk_fma_f32 v[64:65], {w}, v[{x1}:{x1 + 1}], v[64:65] {hi}",
-            f"v_pk_fma_f32 v[66:67], {w}, v[{x1 + 2}:{x1 + 3}], v[66:67] {hi}",
-            "s_set_gpr_idx_off"]
+            f"v_pk_fma_f32 {acc(0)}, {w}, v[{x1}:{x1 + 1}], {acc(0)} {hi}",
+            f"v_pk_fma_f32 {acc(2)}, {w}, v[{x1 + 2}:{x1 + 3}], {acc(2)} {hi}",
+            "s_set_gpr_idx_idx 0" if IDXMODE else "s_set_gpr_idx_off"]
 
 
 def s_readlanes(p):
@@ -170,13 +190,13 @@ def s_readlanes(p):
 
 
 def s_addresses(p):
-    return [f"v_and_or_b32 v44, s{sset(p)['pk0']}, %[mk], %[lb]"]
+    return [f"v_and_or_b32 v{M['a0']}, s{sset(p)['pk0']}, %[mk], %[lb]"]
 
 
 def s_reads(p):
     x0, _ = xreg(p)
     w = wreg(p)
-    return [f"ds_read_b128 v[{x0}:{x0 + 3}], v44"] + ([] if NOWT else [f"ds_read_b64 v[{w}:{w + 1}], %[wb] offset:{8 * p}"])
+    return [f"ds_read_b128 v[{x0}:{x0 + 3}], v{M['a0']}"] + ([] if NOWT else [f"ds_read_b64 v[{w}:{w + 1}], %[wb] offset:{8 * p}"])
 
 
 def s_fmas(p):
@@ -185,14 +205,14 @@ def s_fmas(p):
     x0, _ = xreg(p)
     w = f"v[{wreg(p)}:{wreg(p) + 1}]"
     lo, hi = "op_sel_hi:[0,1,1]", "op_sel:[1,0,0] op_sel_hi:[1,1,1]"
-    return [f"s_set_gpr_idx_on s{s['pk0']}, gpr_idx(SRC2,DST)",
-            f"v_pk_fma_f32 v[64:65], {w}, v[{x0}:{x0 + 1}], v[64:65] {lo}",
-            f"v_pk_fma_f32 v[66:67], {w}, v[{x0 + 2}:{x0 + 3}], v[66:67] {lo}",
+    return [f"s_set_gpr_idx_idx s{s['pk0']}" if IDXMODE else f"s_set_gpr_idx_on s{s['pk0']}, gpr_idx(SRC2,DST)",
+            f"v_pk_fma_f32 {acc(0)}, {w}, v[{x0}:{x0 + 1}], {acc(0)} {lo}",
+            f"v_pk_fma_f32 {acc(2)}, {w}, v[{x0 + 2}:{x0 + 3}], {acc(2)} {lo}",
             f"s_lshr_b32 s{SSLOT}, s{s['pk0']}, 18",
             f"s_set_gpr_idx_idx s{SSLOT}",
-            f"v_pk_fma_f32 v[64:65], {w}, v[{x0}:{x0 + 1}], v[64:65] {hi}",
-            f"v_pk_fma_f32 v[66:67], {w}, v[{x0 + 2}:{x0 + 3}], v[66:67] {hi}",
-            "s_set_gpr_idx_off"]
+            f"v_pk_fma_f32 {acc(0)}, {w}, v[{x0}:{x0 + 1}], {acc(0)} {hi}",
+            f"v_pk_fma_f32 {acc(2)}, {w}, v[{x0 + 2}:{x0 + 3}], {acc(2)} {hi}",
+            "s_set_gpr_idx_idx 0" if IDXMODE else "s_set_gpr_idx_off"]
 
 
 def s_step(p):
@@ -257,8 +277,11 @@ def pre(p0):
     return out
 
 
-def main(path):
+def pipeline_lines():
+    """The whole straight-line pipeline of one chunk for the current register map M."""
     lines = []
+    if IDXMODE:
+        lines += ["s_set_gpr_idx_on 0, gpr_idx(SRC2,DST)"]
     # computed branch: table of s_branch (4 bytes each), indexed by 32 - m
     lines += ["s_getpc_b64 s[94:95]",
               ".Lw4_pc_%=:",
@@ -280,19 +303,37 @@ def main(path):
         for p in range(1, N_PAIRS):
             lines += s_step(p)
         lines.append(".Lw4_end_%=:")
+    if IDXMODE:
+        if not SHARED:
+            lines.append(".Lw4_end_%=:")
+        lines.append("s_set_gpr_idx_off")
     if SMEM:
         lines.append("s_waitcnt lgkmcnt(0)")
-    body = "".join(f'    "{ln}\\n\\t"\n' for ln in lines)
+    return lines
+
+
+def main(path):
+    global M
+    n = 0
     with open(path, "w") as f:
-        f.write("// GENERATED by gen_flat_asm.py - do not edit.  See that file for the register contract.\n")
-        # every register the hand-written statements of agg_tiled_flat4 own, spelled out for their clobber lists (a clobber
-        # list takes single registers, not ranges: naming only the end points would leave the ones in between "free")
-        f.write("#define WGNN_HAND_VGPRS " + ", ".join(f'"v{i}"' for i in range(HAND_VGPR_FIRST, HAND_VGPR_LAST + 1)) + "\n")
+        f.write("// GENERATED by gen_flat_asm.py - do not edit.  See that file for the register contracts.\n")
+        # every register the hand-written statements own, spelled out for their clobber lists (a clobber list takes single
+        # registers, not ranges: naming only the end points would leave the ones in between "free")
+        for name in ("flat", "tall"):
+            lo, hi = MAPS[name]["hand"]
+            f.write(f"#define {MAPS[name]['clob']} " + ", ".join(f'"v{i}"' for i in range(lo, hi + 1)) + "\n")
         f.write("#define WGNN_HAND_SGPRS " + ", ".join(f'"s{i}"' for i in range(HAND_SGPR_FIRST, HAND_SGPR_LAST + 1)) + "\n")
-        f.write("#define WGNN_FLAT4_ASM \\\n")
-        f.write("".join(f'    "{ln}\\n\\t" \\\n' for ln in lines))
-        f.write('    ""\n')
-    return len(lines)
+        for name in ("flat", "tall"):
+            M = MAPS[name]
+            if name == "tall" and (DEPTH != 1 or WRL):
+                continue                                      # the timing experiments exist for the flat map only
+            lines = pipeline_lines()
+            n += len(lines)
+            f.write(f"#define {M['macro']} \\\n")
+            f.write("".join(f'    "{ln}\\n\\t" \\\n' for ln in lines))
+            f.write('    ""\n')
+        M = MAPS["flat"]
+    return n
 
 
 if __name__ == "__main__":

@@ -57,6 +57,7 @@ struct TArgs {
     const int2* tile_hdr;     // [n_tiles] {col_begin, col_end}
     int nblk_max;
     int kb;                   // source rows per LDS block
+    int tall;                 // plan geometry: 0 = 16 waves x 16 rows per tile, 1 = 8 waves x 50 rows (WGNN_PLAN_TALL)
 };
 
 // out[r] = scale[r] * in[r]   (alpha folded into the source table; tiny: |table| bytes)
@@ -178,6 +179,116 @@ __global__ void __launch_bounds__(kTW * 64) agg_tiled(const KArgs a, const TArgs
     }
 }
 
+// Epilogue shared by the two geometries of the flat tile kernel (16 waves x 16 rows, 8 waves x 50 rows): turns the wave's
+// accumulator rows into the kernel's outputs.  `items_base` = first item of this wave (tile * rows per tile + wave * RPW),
+// `acc_row(i)` copies accumulator row i of the wave into compiler registers (literal-register asm of the caller).
+template <typename TOut, int EPI, int RPW, typename AccRow>
+__device__ __forceinline__ void tile_epilogue(const TArgs& t, size_t items_base, int lane, AccRow acc_row) {
+    // The epilogue re-reads its arguments from the kernarg segment through a pointer the optimiser cannot see through:
+    // otherwise every epilogue-only field of `a` (output / self / bias / alpha / inv_deg pointers, strides, partial-sum base)
+    // is loaded in the prologue and kept in SGPRs across the whole block loop, which overflows the s[0:79] the compiler
+    // owns here and spills into VGPR lanes (round 3: 3 .. 20 spilled SGPRs per instantiation, parked in a VGPR outside
+    // the declared budget).  `a` is the kernel's first parameter, i.e. offset 0 of the kernarg segment.
+    typedef const __attribute__((address_space(4))) KArgs* kargs_cptr_t;
+    kargs_cptr_t a_late = (kargs_cptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(a_late));
+    {                                                    // ---- epilogue scope
+    const KArgs a = *(const KArgs*)a_late;                             // shadows the parameter from here on (dead fields are never loaded)
+    const int4* __restrict__ items = t.tile_items + items_base;
+    if constexpr (EPI == EPI_FWD && std::is_same<TOut, float>::value) {
+        if (!a.row_ids) {
+            // Forward epilogue, two rows per trip: the rows' item words come through the scalar cache and the self rows of
+            // BOTH rows are requested before either is used.  The row-at-a-time form below chains an item load, an
+            // inv_deg / alpha load and a self-row load per row - ~2 k clk each, 14 rows per wave, ~10 us per tile of pure
+            // latency (the computing waves of a tile all sit in it at the same time).  Same arithmetic, same order.
+            cptr_t sitems = (cptr_t)items;                      // int4 items as dwords: .x at 4 i, .w at 4 i + 3
+            const bool lane_on = lane * 4 < a.D;
+            const bool no_mean = a.flags & WGNN_FLAG_NO_MEAN, relu = a.flags & WGNN_FLAG_RELU;
+            const bool has_self = !(a.flags & WGNN_FLAG_NO_SELF) && a.self != nullptr;
+            const bool out_scale = (a.flags & WGNN_FLAG_OUT_SCALE_ALPHA) && a.mode == WGNN_DST_IS_GENE;
+            // per-row factors (inv_deg, alpha: inputs nobody writes during the launch) come through the scalar cache like
+            // the item words: the rows are wave-uniform, and as SGPR values they cost no vector registers - the compiler
+            // owns v[0:31] only and this epilogue is the place where it needs them all
+            typedef const __attribute__((address_space(4))) float* cfptr_t;
+            cfptr_t s_alpha = (cfptr_t)a.alpha, s_inv_deg = (cfptr_t)a.inv_deg;
+            const float a_self = has_self ? (a.mode == WGNN_NO_ALPHA ? 1.0f : s_alpha[a.self_idx]) : 0.0f;
+            const float* selfp = reinterpret_cast<const float*>(a.self);
+            float* outp = reinterpret_cast<float*>(a.out);
+            for (int i0 = 0; i0 < RPW; i0 += 2) {
+                int slot[2], pslot[2];
+                float4 sf[2];
+                float invd[2], rs[2], post[2];
+                // the lane's byte offset inside a row, opaque per trip: every access below is then "uniform row base
+                // (SGPR pair) + 32-bit lane offset" - left visible, the offset is folded into each of the four base
+                // pointers ahead of the loop, i.e. four 64-bit per-lane addresses (8 VGPRs) held across it
+                unsigned lo = (unsigned)lane * 16u;
+                asm volatile("" : "+v"(lo));
+                typedef float f4v __attribute__((ext_vector_type(4)));
+                typedef __attribute__((address_space(1))) f4v* gf4_t;                             // global_load / global_store, saddr form
+                auto at = [&](const float* base, size_t row, long ld) {
+                    __attribute__((address_space(1))) char* rb =                                  // wave-uniform row base
+                        (__attribute__((address_space(1))) char*)const_cast<float*>(base + row * ld);
+                    asm volatile("" : "+s"(rb));                                                  // ... kept in an SGPR pair
+                    return (gf4_t)(rb + lo);
+                };
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    slot[k] = -1; pslot[k] = -1;                  // (an odd RPW - the tall tile's 49 - leaves the last trip one row)
+                    if (i0 + k < RPW) { slot[k] = sitems[4 * (i0 + k)]; pslot[k] = sitems[4 * (i0 + k) + 3]; }
+                }
+                float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);     // requested per trip, together with the self rows (1 KiB, L1-resident)
+                if (a.bias && lane_on) { const f4v t = *at(a.bias, 0, 0); bias4 = make_float4(t.x, t.y, t.z, t.w); }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    sf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (slot[k] >= 0 && pslot[k] < 0 && has_self && lane_on)
+                        { const f4v t = *at(selfp, slot[k], a.ld_self); sf[k] = make_float4(t.x, t.y, t.z, t.w); }
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    invd[k] = 1.0f; rs[k] = 1.0f; post[k] = 1.0f;
+                    if (slot[k] >= 0 && pslot[k] < 0) {
+                        if (!no_mean) invd[k] = a.inv_deg ? s_inv_deg[slot[k]] : 1.0f / (row_degree(a, slot[k]) + 1.0f);
+                        const float a_row = a.mode == WGNN_DST_IS_GENE ? s_alpha[slot[k]] : 1.0f;   // one load serves both uses
+                        rs[k] = invd[k] * a_row;
+                        post[k] = a_row;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    if (slot[k] < 0) continue;
+                    float4 o = acc_row(i0 + k);
+                    if (pslot[k] >= 0) {
+                        if (lane_on) *at(a.partials, pslot[k], a.D) = f4v{o.x, o.y, o.z, o.w};
+                        continue;
+                    }
+                    if (a.aux1 && lane_on) *at(a.aux1, slot[k], a.D) = f4v{o.x, o.y, o.z, o.w};                      // raw neighbour sum
+                    o.x *= rs[k]; o.y *= rs[k]; o.z *= rs[k]; o.w *= rs[k];
+                    if (has_self) fma4(o, invd[k] * a_self, sf[k]);
+                    if (a.bias) { o.x += bias4.x; o.y += bias4.y; o.z += bias4.z; o.w += bias4.w; }
+                    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+                    if (out_scale) { o.x *= post[k]; o.y *= post[k]; o.z *= post[k]; o.w *= post[k]; }
+                    if (lane_on) *at(outp, slot[k], a.ld_out) = f4v{o.x, o.y, o.z, o.w};
+                }
+            }
+            return;
+        }
+    }
+    for (int i = 0; i < RPW; ++i) {
+        const int4 it = items[i];
+        const int slot = __builtin_amdgcn_readfirstlane(it.x), pslot = __builtin_amdgcn_readfirstlane(it.w);
+        if (slot < 0) continue;
+        const float4 v = acc_row(i);
+        if (pslot >= 0) {
+            if (lane * 4 < a.D) st4(a.partials + (size_t)pslot * a.D + lane * 4, v);
+        } else {
+            float4 one[1] = {v};
+            epilogue<64, 1, float, TOut, EPI>(a, one, slot, lane, true);
+        }
+    }
+    }                                                    // ---- epilogue scope
+}
+
 // clobber list of a hand-written statement: EVERY register of the hand-owned file by name (gen_flat_asm.py spells them out)
 #define WGNN_CLOB "m0", "memory", "scc", WGNN_HAND_VGPRS, WGNN_HAND_SGPRS
 
@@ -247,10 +358,15 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
     // wave-instruction; the first `nw` waves take part, wave w takes rows w, w + nw, ... (nw = 16: every wave, <= 5 pieces
     // per block; nw = 2 dedicated loader waves: 39 each).  Scalar base + lane offset addressing: no VALU, 6 SALU per row.
     auto fill_rows = [&](int r0, int rows, int buf, int nw) {
-        const int np = rows > wave ? (rows - wave + nw - 1) / nw : 0;
+        // which rows this wave takes: interleaved (w, w + nw, ...) in the general form; a contiguous run when the rows are
+        // equally spaced in global memory and in LDS (the grouped form below rides the instruction's immediate offset)
+        const bool contiguous = g_row == row_bytes && !(DBG && (dbg & kDbgFillToVgpr));
+        const int per = (rows + nw - 1) / nw;
+        const int first = contiguous ? wave * per : wave;
+        const int np = contiguous ? max(0, min(per, rows - first)) : (rows > wave ? (rows - wave + nw - 1) / nw : 0);
         if (np == 0) return;
-        const char* g = reinterpret_cast<const char*>(a.src) + ((size_t)r0 + wave) * g_row;
-        const int l = (int)(size_t)smem + buf * buf_bytes + wave * row_bytes;
+        const char* g = reinterpret_cast<const char*>(a.src) + ((size_t)r0 + first) * g_row;
+        const int l = (int)(size_t)smem + buf * buf_bytes + first * row_bytes;
         if (DBG && (dbg & kDbgFillToVgpr)) {                  // ablation: identical loads, no LDS writes (16-wave form only)
 #define WGNN_FILLV_NEXT(K)                                                                                  \
         "s_cmp_lt_u32 %[np], " #K "\n\ts_cbranch_scc1 .Lw4_fv_%=\n\t"                                        \
@@ -266,13 +382,46 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
             return;
         }
         // EXEC is narrowed to the D/4 lanes that carry data for the duration of the burst (a D < 256 row is shorter than
-        // its 1 KiB LDS slot; the slot's tail is never read by a lane that is stored).  One piece per loop trip: M0 / the
-        // 64-bit source address advance by nw rows.
+        // its 1 KiB LDS slot; the slot's tail is never read by a lane that is stored).
         int left = np;                                        // pieces still to issue (>= 1)
-        // One piece = the DMA, M0 += nw LDS rows, lane offset += nw source rows (v46: a running 32-bit byte offset from the
-        // scalar base - a block's rows span < 4 GiB) - three instructions.  Six pieces per trip while six are left (a
-        // loader wave issues 39 or 78 per block: a lone loader wave is bound by its own instruction issue), then one at a
-        // time.
+        if (g_row == row_bytes) {
+            // Round 5 (scratch/stream_bench2.hip, profiles/r05_stream_bench2.txt).  A wave that advances its address registers
+            // after EVERY piece issues one 1-KiB piece per ~52-63 clk: the update of the lane offset / of M0 waits for the
+            // DMA in front of it to have read them.  The instruction's immediate offset moves BOTH the global and the LDS
+            // address, so when the rows are equally spaced on both sides (D = 64 / 128 / 256: global row = LDS row) four
+            // consecutive rows go out on ONE address setting: 33.6 clk per piece - a lone loader wave streams the cfg3 table
+            // (10.5 GB per pass) in 0.56 ms instead of 1.04 (this loop form; 0.875 with the old loop unrolled by six), and the
+            // advance is scalar (base + M0): the loader wave issues no VALU at all.  The wave takes a CONTIGUOUS run of rows.
+#define WGNN_GROUP4(O1, O2, O3, STEP4, STEP1)                                                                                 \
+            asm volatile("s_mov_b64 s[92:93], exec\n\ts_sub_u32 s91, 64, %[n4]\n\ts_lshr_b64 exec, s[92:93], s91\n\t"           \
+                         "s_mov_b64 s[94:95], %[g]\n\ts_mov_b32 m0, %[l]\n\t"                                                \
+                         "s_cmp_lt_u32 %[left], 4\n\ts_cbranch_scc1 .Lw4_g1_%=\n\t"                                          \
+                         ".Lw4_g4_%=:\n\t"                                                                                   \
+                         "global_load_lds_dwordx4 %[vo], s[94:95]\n\t"                                                        \
+                         "global_load_lds_dwordx4 %[vo], s[94:95] offset:" #O1 "\n\t"                                         \
+                         "global_load_lds_dwordx4 %[vo], s[94:95] offset:" #O2 "\n\t"                                         \
+                         "global_load_lds_dwordx4 %[vo], s[94:95] offset:" #O3 "\n\t"                                         \
+                         "s_add_u32 m0, m0, " #STEP4 "\n\ts_add_u32 s94, s94, " #STEP4 "\n\ts_addc_u32 s95, s95, 0\n\t"        \
+                         "s_sub_u32 %[left], %[left], 4\n\ts_cmp_ge_u32 %[left], 4\n\ts_cbranch_scc1 .Lw4_g4_%=\n\t"         \
+                         "s_cmp_eq_u32 %[left], 0\n\ts_cbranch_scc1 .Lw4_ge_%=\n\t"                                          \
+                         ".Lw4_g1_%=:\n\t"                                                                                   \
+                         "global_load_lds_dwordx4 %[vo], s[94:95]\n\t"                                                        \
+                         "s_add_u32 m0, m0, " #STEP1 "\n\ts_add_u32 s94, s94, " #STEP1 "\n\ts_addc_u32 s95, s95, 0\n\t"        \
+                         "s_sub_u32 %[left], %[left], 1\n\ts_cmp_lg_u32 %[left], 0\n\ts_cbranch_scc1 .Lw4_g1_%=\n\t"         \
+                         ".Lw4_ge_%=:\n\t"                                                                                   \
+                         "s_mov_b64 exec, s[92:93]"                                                                          \
+                         : [left] "+s"(left)                                                                                 \
+                         : [g] "s"(g), [l] "s"(l), [vo] "v"(lane16), [n4] "s"(n4)                                            \
+                         : "m0", "memory", "scc", "s91", "s92", "s93", "s94", "s95")
+            if (row_bytes == 1024) { WGNN_GROUP4(1024, 2048, 3072, 4096, 1024); }
+            else if (row_bytes == 512) { WGNN_GROUP4(512, 1024, 1536, 2048, 512); }
+            else { WGNN_GROUP4(256, 512, 768, 1024, 256); }
+#undef WGNN_GROUP4
+            return;
+        }
+        // Rows spaced differently in global memory and in LDS (D not a power of two): one piece per address setting - the DMA,
+        // M0 += nw LDS rows, lane offset += nw source rows (v46: a running 32-bit byte offset from the scalar base - a block's
+        // rows span < 4 GiB).  Six pieces per trip while six are left, then one at a time.
 #define WGNN_PIECE "global_load_lds_dwordx4 v46, s[94:95]\n\ts_add_u32 m0, m0, %[ms]\n\tv_add_u32 v46, s90, v46\n\t"
         asm volatile("s_mov_b64 s[92:93], exec\n\ts_sub_u32 s91, 64, %[n4]\n\ts_mul_i32 s90, %[n4], %[gs]\n\t"   // s90 = nw rows x D*4 B
                      "s_lshr_b64 exec, s[92:93], s91\n\t"                                                       // lanes 0 .. D/4-1
@@ -410,115 +559,224 @@ agg_tiled_flat4(const KArgs a, const TArgs t) {
         }
     }
 
-    // The epilogue re-reads its arguments from the kernarg segment through a pointer the optimiser cannot see through:
-    // otherwise every epilogue-only field of `a` (output / self / bias / alpha / inv_deg pointers, strides, partial-sum base)
-    // is loaded in the prologue and kept in SGPRs across the whole block loop, which overflows the s[0:79] the compiler
-    // owns here and spills into VGPR lanes (round 3: 3 .. 20 spilled SGPRs per instantiation, parked in a VGPR outside
-    // the declared budget).  `a` is the kernel's first parameter, i.e. offset 0 of the kernarg segment.
-    typedef const __attribute__((address_space(4))) KArgs* kargs_cptr_t;
-    kargs_cptr_t a_late = (kargs_cptr_t)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(a_late));
-    {                                                    // ---- epilogue scope
-    const KArgs a = *(const KArgs*)a_late;                             // shadows the parameter from here on (dead fields are never loaded)
-    const int4* __restrict__ items = t.tile_items + (size_t)tile * kTileRows + wave * kRPW;
-    auto acc_row = [&](int i) {                          // accumulator row i of this wave -> compiler registers
-        float4 v;
+    tile_epilogue<TOut, EPI, kRPW>(t, (size_t)tile * kTileRows + wave * kRPW, lane, [](int i) {
+        float4 v;                                        // accumulator row i of this wave -> compiler registers
         asm volatile("s_set_gpr_idx_on %4, gpr_idx(SRC0)\n\tv_mov_b32 %0, v64\n\tv_mov_b32 %1, v65\n\t"
                      "v_mov_b32 %2, v66\n\tv_mov_b32 %3, v67\n\ts_set_gpr_idx_off"
                      : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w) : "s"(i * 4) : "m0");
         return v;
-    };
-    if constexpr (EPI == EPI_FWD && std::is_same<TOut, float>::value) {
-        if (!a.row_ids) {
-            // Forward epilogue, two rows per trip: the rows' item words come through the scalar cache and the self rows of
-            // BOTH rows are requested before either is used.  The row-at-a-time form below chains an item load, an
-            // inv_deg / alpha load and a self-row load per row - ~2 k clk each, 14 rows per wave, ~10 us per tile of pure
-            // latency (the computing waves of a tile all sit in it at the same time).  Same arithmetic, same order.
-            cptr_t sitems = (cptr_t)items;                      // int4 items as dwords: .x at 4 i, .w at 4 i + 3
-            const bool lane_on = lane * 4 < a.D;
-            const bool no_mean = a.flags & WGNN_FLAG_NO_MEAN, relu = a.flags & WGNN_FLAG_RELU;
-            const bool has_self = !(a.flags & WGNN_FLAG_NO_SELF) && a.self != nullptr;
-            const bool out_scale = (a.flags & WGNN_FLAG_OUT_SCALE_ALPHA) && a.mode == WGNN_DST_IS_GENE;
-            // per-row factors (inv_deg, alpha: inputs nobody writes during the launch) come through the scalar cache like
-            // the item words: the rows are wave-uniform, and as SGPR values they cost no vector registers - the compiler
-            // owns v[0:31] only and this epilogue is the place where it needs them all
-            typedef const __attribute__((address_space(4))) float* cfptr_t;
-            cfptr_t s_alpha = (cfptr_t)a.alpha, s_inv_deg = (cfptr_t)a.inv_deg;
-            const float a_self = has_self ? (a.mode == WGNN_NO_ALPHA ? 1.0f : s_alpha[a.self_idx]) : 0.0f;
-            const float* selfp = reinterpret_cast<const float*>(a.self);
-            float* outp = reinterpret_cast<float*>(a.out);
-            for (int i0 = 0; i0 < kRPW; i0 += 2) {
-                int slot[2], pslot[2];
-                float4 sf[2];
-                float invd[2], rs[2], post[2];
-                // the lane's byte offset inside a row, opaque per trip: every access below is then "uniform row base
-                // (SGPR pair) + 32-bit lane offset" - left visible, the offset is folded into each of the four base
-                // pointers ahead of the loop, i.e. four 64-bit per-lane addresses (8 VGPRs) held across it
-                unsigned lo = (unsigned)lane * 16u;
-                asm volatile("" : "+v"(lo));
-                typedef float f4v __attribute__((ext_vector_type(4)));
-                typedef __attribute__((address_space(1))) f4v* gf4_t;                             // global_load / global_store, saddr form
-                auto at = [&](const float* base, size_t row, long ld) {
-                    __attribute__((address_space(1))) char* rb =                                  // wave-uniform row base
-                        (__attribute__((address_space(1))) char*)const_cast<float*>(base + row * ld);
-                    asm volatile("" : "+s"(rb));                                                  // ... kept in an SGPR pair
-                    return (gf4_t)(rb + lo);
-                };
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    slot[k] = sitems[4 * (i0 + k)]; pslot[k] = sitems[4 * (i0 + k) + 3];
-                }
-                float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);     // requested per trip, together with the self rows (1 KiB, L1-resident)
-                if (a.bias && lane_on) { const f4v t = *at(a.bias, 0, 0); bias4 = make_float4(t.x, t.y, t.z, t.w); }
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    sf[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (slot[k] >= 0 && pslot[k] < 0 && has_self && lane_on)
-                        { const f4v t = *at(selfp, slot[k], a.ld_self); sf[k] = make_float4(t.x, t.y, t.z, t.w); }
-                }
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    invd[k] = 1.0f; rs[k] = 1.0f; post[k] = 1.0f;
-                    if (slot[k] >= 0 && pslot[k] < 0) {
-                        if (!no_mean) invd[k] = a.inv_deg ? s_inv_deg[slot[k]] : 1.0f / (row_degree(a, slot[k]) + 1.0f);
-                        const float a_row = a.mode == WGNN_DST_IS_GENE ? s_alpha[slot[k]] : 1.0f;   // one load serves both uses
-                        rs[k] = invd[k] * a_row;
-                        post[k] = a_row;
-                    }
-                }
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    if (slot[k] < 0) continue;
-                    float4 o = acc_row(i0 + k);
-                    if (pslot[k] >= 0) {
-                        if (lane_on) *at(a.partials, pslot[k], a.D) = f4v{o.x, o.y, o.z, o.w};
-                        continue;
-                    }
-                    if (a.aux1 && lane_on) *at(a.aux1, slot[k], a.D) = f4v{o.x, o.y, o.z, o.w};                      // raw neighbour sum
-                    o.x *= rs[k]; o.y *= rs[k]; o.z *= rs[k]; o.w *= rs[k];
-                    if (has_self) fma4(o, invd[k] * a_self, sf[k]);
-                    if (a.bias) { o.x += bias4.x; o.y += bias4.y; o.z += bias4.z; o.w += bias4.w; }
-                    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
-                    if (out_scale) { o.x *= post[k]; o.y *= post[k]; o.z *= post[k]; o.w *= post[k]; }
-                    if (lane_on) *at(outp, slot[k], a.ld_out) = f4v{o.x, o.y, o.z, o.w};
-                }
-            }
+    });
+}
+
+// ---------------------------------------------------------------------------------------------
+// agg_tiled_tall (round 5) - the same entry pipeline on a TALL tile: 8 waves x 256 VGPRs, 49 destination rows per wave,
+// 392 per tile.  Why: scratch/pipe_bench (profiles/r05_pipe_bench.txt) prices an entry of the pipeline at 2.73 / 1.88 ns per
+// CU (unshared / shared pair) with 16 waves and 2.86 / 1.94 ns with 8 - two waves per SIMD cost 5 %, not the 30 % of the
+// round-1 pipeline - while the 16-wave kernel spends ~35 % of a cfg3 pass outside that steady state: per-(wave, block)
+// prologues, warm-ups and drains over ~47 entries, one barrier per block, and TWO tiles per CU (512 tiles of 195 rows), each
+// streaming the whole source table.  A 392-row tile covers cfg3's 100 000 rows in ONE round of 256 tiles: the table is
+// streamed once per CU, a (wave, block) segment holds ~150 entries (3 chunks), and 49 rows per wave share LDS rows more often
+// (79 % of the entries pair up, 55 % at 13 rows).
+//   Register file: the compiler may allocate v[0:41] (amdgpu_num_vgpr(21)).  v[20:41] are the pipeline's staging / weight /
+//   address registers: STATEMENT-LOCAL (dead between asm statements, named as clobbers), so the compiler may use them
+//   between statements and in the epilogue but never across one (an asm operand is never given a clobbered register).
+//   v[42:43] segment bounds, v[44:59] entry chunks (two block sets x four chunks x {meta, weight}) and the accumulators
+//   v[60:255] carry state across statements and lie beyond the compiler's cap (build.audit enforces it).
+//   Entry chunks: at the top of block b the (up to) four chunks of block b+1 are requested into the other set; one
+//   `s_waitcnt vmcnt(0)` at the next top covers them, the DMA pieces of the block and the segment bounds of block b+2.
+//   Every wave streams its contiguous share of a block (grouped immediate-offset form: no dedicated loader wave - with
+//   8 waves there is none to spare, and ~10 pieces per wave and block are ~350 clk of ~7 k).
+// ---------------------------------------------------------------------------------------------
+constexpr int kTallTW = 8, kTallRPW = 49, kTallRows = kTallTW * kTallRPW, kTallNCH = 4;
+#define WGNN_TALL_CLOB "m0", "memory", "scc", WGNN_TALL_VGPRS, WGNN_HAND_SGPRS
+
+template <int SET, int J> __device__ __forceinline__ int2 tall_chunk_get() {
+    int2 e;
+#define WGNN_TCG(S_, J_, A_, B_) \
+    if constexpr (SET == S_ && J == J_) asm volatile("v_mov_b32 %0, " A_ "\n\tv_mov_b32 %1, " B_ : "=v"(e.x), "=v"(e.y)::"memory");
+    WGNN_TCG(0, 0, "v44", "v45") WGNN_TCG(0, 1, "v46", "v47") WGNN_TCG(0, 2, "v48", "v49") WGNN_TCG(0, 3, "v50", "v51")
+    WGNN_TCG(1, 0, "v52", "v53") WGNN_TCG(1, 1, "v54", "v55") WGNN_TCG(1, 2, "v56", "v57") WGNN_TCG(1, 3, "v58", "v59")
+#undef WGNN_TCG
+    return e;
+}
+template <int SET, int J> __device__ __forceinline__ void tall_chunk_load(int off, const int2* base) {
+#define WGNN_TCL(S_, J_, R_, A_, B_) \
+    if constexpr (SET == S_ && J == J_) asm volatile("global_load_dwordx2 " R_ ", %0, %1" ::"v"(off), "s"(base) : "memory", A_, B_);
+    WGNN_TCL(0, 0, "v[44:45]", "v44", "v45") WGNN_TCL(0, 1, "v[46:47]", "v46", "v47") WGNN_TCL(0, 2, "v[48:49]", "v48", "v49")
+    WGNN_TCL(0, 3, "v[50:51]", "v50", "v51") WGNN_TCL(1, 0, "v[52:53]", "v52", "v53") WGNN_TCL(1, 1, "v[54:55]", "v54", "v55")
+    WGNN_TCL(1, 2, "v[56:57]", "v56", "v57") WGNN_TCL(1, 3, "v[58:59]", "v58", "v59")
+#undef WGNN_TCL
+}
+
+template <typename TOut, int EPI, bool DBG>
+__global__ void __launch_bounds__(kTallTW * 64) __attribute__((amdgpu_num_vgpr(21)))
+agg_tiled_tall(const KArgs a, const TArgs t) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int row_bytes = flat_lds_row_bytes(a.D);
+    const int g_row = a.D * (int)sizeof(float);
+    const int n4 = a.D >> 2;
+    const int kKB = t.kb, buf_bytes = kKB * row_bytes;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int tile = blockIdx.x;
+    const int2 hdr = t.tile_hdr[tile];
+    const int cb = __builtin_amdgcn_readfirstlane(hdr.x), ce = __builtin_amdgcn_readfirstlane(hdr.y);
+    const int nblk = (ce - cb + kKB - 1) / kKB;
+    const int* seg = t.seg_ptr + ((size_t)tile * t.nblk_max) * kTallTW + wave;     // seg[b*8], seg[b*8+1]
+    const unsigned dbg = DBG ? a.flags : 0u;
+    const bool do_fill = !(dbg & kDbgNoFill), do_comp = !(dbg & kDbgNoCompute), do_barrier = !(dbg & kDbgNoBarrier);
+
+    for (int r = 0; r < kTallRPW; ++r)                   // zero the accumulators v[60:259]
+        asm volatile("s_set_gpr_idx_on %0, gpr_idx(DST)\n\tv_mov_b32 v60, 0\n\tv_mov_b32 v61, 0\n\t"
+                     "v_mov_b32 v62, 0\n\tv_mov_b32 v63, 0\n\ts_set_gpr_idx_off" ::"s"(r * 4) : WGNN_TALL_CLOB);
+
+    const int lane16 = lane * 16, row_mask = 0x3FF00;
+    // this wave's share of the global -> LDS DMA of `rows` source rows (see agg_tiled_flat4::fill_rows for the two forms)
+    // `part` of `parts`: the wave's run of pieces may be issued in portions at its chunk boundaries instead of one burst at the
+    // top of the block (contiguous form only; see kParts below for what was measured).
+    auto fill_rows = [&](int r0, int rows, int buf, int part, int parts) {
+        constexpr int nw = kTallTW;
+        const bool contiguous = g_row == row_bytes;
+        const int per = (rows + nw - 1) / nw;
+        int first = contiguous ? wave * per : wave;
+        int np = contiguous ? max(0, min(per, rows - first)) : (rows > wave ? (rows - wave + nw - 1) / nw : 0);
+        if (contiguous) {                                     // this portion: pieces [part * q, (part + 1) * q) of the run, q = ceil(np / parts)
+            const int q = (np + parts - 1) / parts, lo = min(np, part * q);
+            np = min(np, lo + q) - lo;
+            first += lo;
+        } else if (part != 0) {
+            np = 0;                                           // the general form goes out in one burst with portion 0
+        }
+        if (np == 0) return;
+        const char* g = reinterpret_cast<const char*>(a.src) + ((size_t)r0 + first) * g_row;
+        const int l = (int)(size_t)smem + buf * buf_bytes + first * row_bytes;
+        int left = np;
+        if (contiguous) {
+#define WGNN_GROUP4(O1, O2, O3, STEP4, STEP1)                                                                                 \
+            asm volatile("s_mov_b64 s[92:93], exec\n\ts_sub_u32 s91, 64, %[n4]\n\ts_lshr_b64 exec, s[92:93], s91\n\t"           \
+                         "s_mov_b64 s[94:95], %[g]\n\ts_mov_b32 m0, %[l]\n\t"                                                \
+                         "s_cmp_lt_u32 %[left], 4\n\ts_cbranch_scc1 .Lw8_g1_%=\n\t"                                          \
+                         ".Lw8_g4_%=:\n\t"                                                                                   \
+                         "global_load_lds_dwordx4 %[vo], s[94:95]\n\t"                                                        \
+                         "global_load_lds_dwordx4 %[vo], s[94:95] offset:" #O1 "\n\t"                                         \
+                         "global_load_lds_dwordx4 %[vo], s[94:95] offset:" #O2 "\n\t"                                         \
+                         "global_load_lds_dwordx4 %[vo], s[94:95] offset:" #O3 "\n\t"                                         \
+                         "s_add_u32 m0, m0, " #STEP4 "\n\ts_add_u32 s94, s94, " #STEP4 "\n\ts_addc_u32 s95, s95, 0\n\t"        \
+                         "s_sub_u32 %[left], %[left], 4\n\ts_cmp_ge_u32 %[left], 4\n\ts_cbranch_scc1 .Lw8_g4_%=\n\t"         \
+                         "s_cmp_eq_u32 %[left], 0\n\ts_cbranch_scc1 .Lw8_ge_%=\n\t"                                          \
+                         ".Lw8_g1_%=:\n\t"                                                                                   \
+                         "global_load_lds_dwordx4 %[vo], s[94:95]\n\t"                                                        \
+                         "s_add_u32 m0, m0, " #STEP1 "\n\ts_add_u32 s94, s94, " #STEP1 "\n\ts_addc_u32 s95, s95, 0\n\t"        \
+                         "s_sub_u32 %[left], %[left], 1\n\ts_cmp_lg_u32 %[left], 0\n\ts_cbranch_scc1 .Lw8_g1_%=\n\t"         \
+                         ".Lw8_ge_%=:\n\t"                                                                                   \
+                         "s_mov_b64 exec, s[92:93]"                                                                          \
+                         : [left] "+s"(left)                                                                                 \
+                         : [g] "s"(g), [l] "s"(l), [vo] "v"(lane16), [n4] "s"(n4)                                            \
+                         : "m0", "memory", "scc", "s91", "s92", "s93", "s94", "s95")
+            if (row_bytes == 1024) { WGNN_GROUP4(1024, 2048, 3072, 4096, 1024); }
+            else if (row_bytes == 512) { WGNN_GROUP4(512, 1024, 1536, 2048, 512); }
+            else { WGNN_GROUP4(256, 512, 768, 1024, 256); }
+#undef WGNN_GROUP4
             return;
         }
-    }
-    for (int i = 0; i < kRPW; ++i) {
-        const int4 it = items[i];
-        const int slot = __builtin_amdgcn_readfirstlane(it.x), pslot = __builtin_amdgcn_readfirstlane(it.w);
-        if (slot < 0) continue;
-        const float4 v = acc_row(i);
-        if (pslot >= 0) {
-            if (lane * 4 < a.D) st4(a.partials + (size_t)pslot * a.D + lane * 4, v);
-        } else {
-            float4 one[1] = {v};
-            epilogue<64, 1, float, TOut, EPI>(a, one, slot, lane, true);
+        // global row shorter than its LDS slot: one piece per address setting (v41: a statement-local running lane offset)
+        asm volatile("s_mov_b64 s[92:93], exec\n\ts_sub_u32 s91, 64, %[n4]\n\ts_mul_i32 s90, %[n4], %[gs]\n\t"
+                     "s_lshr_b64 exec, s[92:93], s91\n\t"
+                     "s_mov_b64 s[94:95], %[g]\n\ts_mov_b32 m0, %[l]\n\tv_mov_b32 v41, %[vo]\n\t"
+                     ".Lw8_f1_%=:\n\t"
+                     "global_load_lds_dwordx4 v41, s[94:95]\n\ts_add_u32 m0, m0, %[ms]\n\tv_add_u32 v41, s90, v41\n\t"
+                     "s_sub_u32 %[left], %[left], 1\n\ts_cmp_lg_u32 %[left], 0\n\ts_cbranch_scc1 .Lw8_f1_%=\n\t"
+                     "s_mov_b64 exec, s[92:93]"
+                     : [left] "+s"(left)
+                     : [g] "s"(g), [l] "s"(l), [vo] "v"(lane16), [n4] "s"(n4), [ms] "s"(nw * row_bytes), [gs] "s"(nw * 16)
+                     : "m0", "memory", "scc", "s90", "s91", "s92", "s93", "s94", "s95", "v41");
+    };
+    // kParts = 1: one burst at the top of the block.  Portions at the chunk boundaries (kParts = 3) measured WORSE (cfg3
+    // cells<-genes 1.236 vs 1.166 ms): a global_load_lds issued by a wave that also runs the entry pipeline costs ~150 clk, not the
+    // ~34 clk of a wave that does nothing else - which is what the 16-wave kernel's dedicated loader wave is for.
+    constexpr int kParts = 1;
+    auto fill = [&](int b, int part, int parts) { fill_rows(cb + b * kKB, min(kKB, ce - (cb + b * kKB)), b & 1, part, parts); };
+    // chunk j of segment [s, e) -> chunk register j of set SET, RIGHT-aligned (lane i <- entry s + 64 j + i - (64 - n));
+    // nothing is requested for an empty chunk (the block's single vmcnt(0) needs no load count)
+    auto chunk_issue = [&](auto set, auto jj, int s, int e) {
+        constexpr int SET = decltype(set)::value, J = decltype(jj)::value;
+        const int n = min(64, e - (s + 64 * J));
+        if (n <= 0) return;
+        tall_chunk_load<SET, J>(max(lane - (64 - n), 0) * 8, t.entries + s + 64 * J);
+    };
+    auto chunks_issue = [&](auto set, int s, int e) {
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        chunk_issue(set, I0{}, s, e); chunk_issue(set, I1{}, s, e); chunk_issue(set, I2{}, s, e); chunk_issue(set, I3{}, s, e);
+    };
+    auto seg_load = [&](const int* p) {                   // {begin, end} of one (block, wave) -> v[42:43]
+        asm volatile("global_load_dwordx2 v[42:43], %0, %1" ::"v"(0), "s"(p) : "memory", "v42", "v43");
+    };
+    const int wstrip_addr = (int)(size_t)smem + 2 * buf_bytes + wave * 256;
+    const int wlane_addr = wstrip_addr + lane * 4;
+    auto consume = [&](const int2& ent, int n, int buf_addr) {
+        // packed entry: LDS address of the source row (bits 8..17) | 4*slot (bits 0..7) | 4*slot of a shared pair's second
+        // entry (bits 18..25) - slots are 6 bits wide here (49 rows per wave)
+        const int pk = (buf_addr + (ent.x & 0xFF) * row_bytes) | (((ent.x >> 8) & 0x3F) << 2) | (((ent.x >> 16) & 0x3F) << 20);
+        const bool mine = lane >= 64 - n;
+        const int wv = mine ? ent.y : 0;
+        const int m = (n + 1) >> 1;
+        const int n_s = __popcll(__ballot(mine && ent.x < 0));
+        const int sw = max(32 - (n_s >> 1), 33 - m);
+        asm volatile("ds_write_b32 %[wa], %[wv]\n\t" WGNN_TALL_ASM
+                     ::[pk] "v"(pk), [wa] "v"(wlane_addr), [wv] "v"(wv), [wb] "v"(wstrip_addr), [lb] "v"(lane16),
+                       [mk] "v"(row_mask), [m] "s"(m), [sw] "s"(sw)
+                     : WGNN_TALL_CLOB);
+    };
+    // `nb` >= 0: block nb's DMA portions 1 and 2 go out behind this block's first and second chunk (portion 0 went out at the top)
+    auto compute = [&](auto set, int cs, int ce0, int buf_addr, int nb) {
+        constexpr int SET = decltype(set)::value;
+        if (cs + 0 < ce0) consume(tall_chunk_get<SET, 0>(), min(64, ce0 - cs), buf_addr);
+        if (nb >= 0) fill(nb, 1, kParts);
+        if (cs + 64 < ce0) consume(tall_chunk_get<SET, 1>(), min(64, ce0 - cs - 64), buf_addr);
+        if (nb >= 0) fill(nb, 2, kParts);
+        if (cs + 128 < ce0) consume(tall_chunk_get<SET, 2>(), min(64, ce0 - cs - 128), buf_addr);
+        if (cs + 192 < ce0) consume(tall_chunk_get<SET, 3>(), min(64, ce0 - cs - 192), buf_addr);
+        for (int s = cs + 64 * kTallNCH; s < ce0; s += 64) {   // rare: more than 256 entries for this wave in one block
+            const int n = min(64, ce0 - s);
+            tall_chunk_load<SET, 0>(max(lane - (64 - n), 0) * 8, t.entries + s);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the next block's requests are in flight behind it: wait for all)
+            consume(tall_chunk_get<SET, 0>(), n, buf_addr);
+        }
+    };
+    // One source block.  SET = chunk set of block b; (cs, ce0) = this block's segment; (ns, ne) receive block b+1's.
+    auto block = [&](auto set, auto other, int b, int cs, int ce0, int& ns, int& ne) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // my DMA pieces of block b, my chunks of block b, the bounds of block b+1
+        if (do_barrier) __builtin_amdgcn_s_barrier();       // everyone's pieces landed; everyone is done with block b-1
+        if (b + 1 < nblk) {
+            asm volatile("v_readfirstlane_b32 %0, v42\n\tv_readfirstlane_b32 %1, v43" : "=s"(ns), "=s"(ne)::"memory");
+            if (b + 2 < nblk) seg_load(seg + (b + 2) * kTallTW);
+            if (do_fill) fill(b + 1, 0, kParts);
+            chunks_issue(other, ns, ne);
+        }
+        const int nb = (b + 1 < nblk && do_fill) ? b + 1 : -1;
+        if (do_comp) compute(set, cs, ce0, (int)(size_t)smem + (b & 1) * buf_bytes, nb);
+        else if (nb >= 0) { fill(nb, 1, kParts); fill(nb, 2, kParts); }
+    };
+    if (nblk > 0) {
+        using S0 = std::integral_constant<int, 0>; using S1 = std::integral_constant<int, 1>;
+        cptr_t sseg = (cptr_t)seg;                        // the first segment through the scalar cache
+        int sA = sseg[0], eA = sseg[1], sB = 0, eB = 0;
+        if (nblk > 1) seg_load(seg + kTallTW);
+        if (do_fill) fill(0, 0, 1);
+        chunks_issue(S0{}, sA, eA);
+        for (int b = 0; b < nblk; b += 2) {                   // two blocks per trip: the chunk sets swap roles statically
+            block(S0{}, S1{}, b, sA, eA, sB, eB);
+            if (b + 1 < nblk) block(S1{}, S0{}, b + 1, sB, eB, sA, eA);
         }
     }
-    }                                                    // ---- epilogue scope
+    tile_epilogue<TOut, EPI, kTallRPW>(t, (size_t)tile * kTallRows + wave * kTallRPW, lane, [](int i) {
+        float4 v;
+        asm volatile("s_set_gpr_idx_on %4, gpr_idx(SRC0)\n\tv_mov_b32 %0, v60\n\tv_mov_b32 %1, v61\n\t"
+                     "v_mov_b32 %2, v62\n\tv_mov_b32 %3, v63\n\ts_set_gpr_idx_off"
+                     : "=v"(v.x), "=v"(v.y), "=v"(v.z), "=v"(v.w) : "s"(i * 4) : "m0");
+        return v;
+    });
 }
 
 // LDS bytes of one launch: the flat kernel's LDS rows are 256 / 512 / 1024 bytes (+ the per-wave weight strips)
@@ -547,8 +805,17 @@ template <typename TOut, int EPI>
 int launch_tiled(const KArgs& a, const TArgs& t, long n_tiles, hipStream_t st) {
     const int lds = (int)tiled_lds_bytes(a.D, t.kb, a.flags);
     if (lds > 160 * 1024) return WGNN_ERR_PLAN;
-    static LdsMarks generic_marks{}, flat_marks{}, flat_dbg_marks{};      // per instantiation, per device
-    if (use_flat(a.D, a.flags)) {
+    static LdsMarks generic_marks{}, flat_marks{}, flat_dbg_marks{}, tall_marks{}, tall_dbg_marks{};      // per instantiation, per device
+    if (t.tall) {
+        if (!use_flat(a.D, a.flags)) return WGNN_ERR_PLAN;          // a tall plan has no generic-kernel form
+        if (a.flags & 0xFFFF0000u) {                                // timing-experiment switches: the instantiation that reads them
+            if (int rc = raise_lds_limit(tall_dbg_marks, reinterpret_cast<const void*>(&agg_tiled_tall<TOut, EPI, true>), lds)) return rc;
+            hipLaunchKernelGGL((agg_tiled_tall<TOut, EPI, true>), dim3((unsigned)n_tiles), dim3(kTallTW * 64), lds, st, a, t);
+        } else {
+            if (int rc = raise_lds_limit(tall_marks, reinterpret_cast<const void*>(&agg_tiled_tall<TOut, EPI, false>), lds)) return rc;
+            hipLaunchKernelGGL((agg_tiled_tall<TOut, EPI, false>), dim3((unsigned)n_tiles), dim3(kTallTW * 64), lds, st, a, t);
+        }
+    } else if (use_flat(a.D, a.flags)) {
         if (int rc = raise_lds_limit(flat_marks, reinterpret_cast<const void*>(&agg_tiled_flat4<TOut, EPI, false>), lds)) return rc;
         if (a.flags & 0xFFFF0000u)
             if (int rc = raise_lds_limit(flat_dbg_marks, reinterpret_cast<const void*>(&agg_tiled_flat4<TOut, EPI, true>), lds)) return rc;
@@ -562,6 +829,10 @@ int launch_tiled(const KArgs& a, const TArgs& t, long n_tiles, hipStream_t st) {
     }
     return hipGetLastError() == hipSuccess ? WGNN_OK : WGNN_ERR_LAUNCH;
 }
+
+// `block_rows` of the tiled entry points carries the plan's geometry in its high half (include/wgnn.h: WGNN_PLAN_TALL)
+inline int plan_rows(int32_t block_rows) { return block_rows & 0xFFFF; }
+inline int plan_tall(int32_t block_rows) { return (block_rows & WGNN_PLAN_TALL) ? 1 : 0; }
 
 }  // namespace
 
@@ -584,6 +855,9 @@ extern "C" int wgnn_agg_fwd_tiled(const void* rowptr, const float* alpha, int al
     if (!inv_deg && !rowptr && !(flags & WGNN_FLAG_NO_MEAN)) return WGNN_ERR_BAD_ARG;
     if (D <= 0 || D % 4 || ld_out % 4 || (h_self && ld_self % 4)) return WGNN_ERR_ALIGNMENT;
     if (D > 256) return WGNN_ERR_UNSUPPORTED;                     // one float4 per lane
+    const int tall = plan_tall(block_rows);
+    if (block_rows & ~(0xFFFF | WGNN_PLAN_TALL)) return WGNN_ERR_PLAN;
+    block_rows = plan_rows(block_rows);
     if (block_rows < 16 || block_rows > 255 || tiled_lds_bytes(D, block_rows, flags) > 160 * 1024) return WGNN_ERR_PLAN;
     if (!aligned16(h_src) || !aligned16(out) || (h_self && !aligned16(h_self)) || (bias && !aligned16(bias)))
         return WGNN_ERR_ALIGNMENT;
@@ -608,7 +882,7 @@ extern "C" int wgnn_agg_fwd_tiled(const void* rowptr, const float* alpha, int al
     if (neigh_sum && !aligned16(neigh_sum)) return WGNN_ERR_ALIGNMENT;
     a.long_rows = reinterpret_cast<const int4*>(long_rows); a.n_long = n_long; a.partials = partials;
     TArgs t{reinterpret_cast<const int2*>(entries), seg_ptr, reinterpret_cast<const int4*>(tile_items),
-            reinterpret_cast<const int2*>(tile_hdr), nblk_max, block_rows};
+            reinterpret_cast<const int2*>(tile_hdr), nblk_max, block_rows, tall};
     int rc = launch_tiled<float, EPI_FWD>(a, t, n_tiles, st);
     if (rc) return rc;
     if (n_long > 0) return launch_finalize_f32(a, EPI_FWD, st);
@@ -621,6 +895,8 @@ static int tiled_common_check(int32_t D, int32_t block_rows, const void* entries
                               const float* partials, int64_t n_partials) {
     if (D <= 0 || D % 4) return WGNN_ERR_ALIGNMENT;
     if (D > 256) return WGNN_ERR_UNSUPPORTED;
+    if (block_rows & ~(0xFFFF | WGNN_PLAN_TALL)) return WGNN_ERR_PLAN;
+    block_rows = plan_rows(block_rows);
     if (block_rows < 16 || block_rows > 255 || tiled_lds_bytes(D, block_rows, 0) > 160 * 1024) return WGNN_ERR_PLAN;
     if (n_tiles < 0 || (n_tiles > 0 && (!tile_items || !tile_hdr || !entries || !seg_ptr))) return WGNN_ERR_BAD_ARG;
     if (n_long > 0 && (!long_rows || !partials || n_partials <= 0)) return WGNN_ERR_WORKSPACE;
@@ -657,7 +933,7 @@ extern "C" int wgnn_agg_bwd_src_tiled(const float* alpha, int alpha_mode, const 
     a.D = D; a.flags = WGNN_FLAG_NO_MEAN; a.accumulate = accumulate;
     a.long_rows = reinterpret_cast<const int4*>(long_rows); a.n_long = n_long; a.partials = partials;
     TArgs t{reinterpret_cast<const int2*>(entries), seg_ptr, reinterpret_cast<const int4*>(tile_items),
-            reinterpret_cast<const int2*>(tile_hdr), nblk_max, block_rows};
+            reinterpret_cast<const int2*>(tile_hdr), nblk_max, plan_rows(block_rows), plan_tall(block_rows)};
     rc = launch_tiled<float, EPI_BWD_SRC>(a, t, n_tiles, st);
     if (rc) return rc;
     if (n_long > 0) return launch_finalize_f32(a, EPI_BWD_SRC, st);
@@ -684,7 +960,7 @@ extern "C" int wgnn_agg_bwd_alpha_tiled(const float* inv_deg, const float* g, in
     a.D = D; a.flags = 0;
     a.long_rows = reinterpret_cast<const int4*>(long_rows); a.n_long = n_long; a.partials = partials;
     TArgs t{reinterpret_cast<const int2*>(entries), seg_ptr, reinterpret_cast<const int4*>(tile_items),
-            reinterpret_cast<const int2*>(tile_hdr), nblk_max, block_rows};
+            reinterpret_cast<const int2*>(tile_hdr), nblk_max, plan_rows(block_rows), plan_tall(block_rows)};
     hipStream_t st = static_cast<hipStream_t>(stream);
     rc = launch_tiled<float, EPI_BWD_ALPHA>(a, t, n_tiles, st);
     if (rc) return rc;

@@ -241,15 +241,17 @@ class AggCsr:
         off the plan like the forward, and were measured that way (training step 10.7 -> 10.1 -> 9.9 ms in round 3)."""
         if self._tile_plan is None:
             self._tile_plan = {}
-        key = (block_rows, TILE_LOADER_WAVES if loaders is None else loaders, TILE_SHARED_PAIRS, self.cu_budget)
+        tall = TILE_SHARED_PAIRS and (TILE_TALL == "on" or (TILE_TALL == "auto" and self.n_rows >= TALL_MIN_ROWS))
+        geom = GEOM_TALL if tall else GEOM_FLAT
+        key = (block_rows, TILE_LOADER_WAVES if loaders is None else loaders, TILE_SHARED_PAIRS, self.cu_budget, geom)
         if key not in self._tile_plan:
-            tp = build_tile_plan(self, None, None, n_cus=self.cu_budget, block_rows=block_rows, n_loaders=key[1])
+            tp = build_tile_plan(self, None, None, n_cus=self.cu_budget, block_rows=block_rows, n_loaders=key[1], geom=geom)
             if self.cu_budget < 256 and tp.n_tiles > self.cu_budget:
                 # A tile workgroup takes a whole CU (16 waves x 128 VGPRs, 160 KB LDS).  In a ONE-round launch every CU held
                 # by another kernel pushes a tile into a second round (+55 .. +65 % per pass next to 16 - 32 held CUs,
                 # profiles/r04_issue_analysis.md section 10); a launch of several rounds re-balances by itself, and shrinking
                 # its rounds would only cost the uncontended case - it keeps the full chip.
-                tp = build_tile_plan(self, None, None, block_rows=block_rows, n_loaders=key[1])
+                tp = build_tile_plan(self, None, None, block_rows=block_rows, n_loaders=key[1], geom=geom)
             self._tile_plan[key] = tp
         return self._tile_plan[key]
 
@@ -452,6 +454,31 @@ class CellGeneGraph:
 # ------------------------------------------------------------------------------------------------
 TILE_ROWS = 256          # 16 waves x 16 rows (kTW x kRPW in csrc/wgnn_tiled.hip)
 TILE_WAVES = 16
+
+
+@dataclass(frozen=True)
+class TileGeom:
+    """Tile geometry of a plan: waves per tile workgroup x destination rows per wave (csrc/wgnn_tiled.hip)."""
+    waves: int
+    rpw: int
+    tall: bool = False
+
+    @property
+    def rows(self) -> int:
+        return self.waves * self.rpw
+
+
+GEOM_FLAT = TileGeom(TILE_WAVES, TILE_ROWS // TILE_WAVES)      # agg_tiled_flat4 / agg_tiled: 16 waves x 16 rows, 128 VGPRs per wave
+GEOM_TALL = TileGeom(8, 49, True)                              # agg_tiled_tall (round 5): 8 waves x 49 rows, 256 VGPRs per wave
+# Which operands get the tall tile: "off" (default) never; "auto" many-row operands without a column split - the cell side of a
+# graph, the transposed gene side in training; "on" every operand.  One 392-row tile per CU covers cfg3's 100 000 rows in ONE
+# round (the table is streamed once per CU instead of twice, ~150 entries per (wave, block) instead of ~47).  MEASURED SLOWER
+# than the 16-wave kernel at cfg3 (profiles/r05_issue_analysis.md: cells<-genes 1.17 vs 1.06 ms): its entry pipeline is on par
+# (0.985 vs 1.01 ms without the table stream), but with 8 waves x 256 VGPRs there is no wave to spare for a dedicated loader and
+# the DMA issued by the computing waves costs +0.18 ms.  Kept opt-in (parity-tested, register contract audited) as the base for a
+# tall tile WITH a loader.
+TILE_TALL = __import__("os").environ.get("WGNN_TILE_TALL", "off")
+TALL_MIN_ROWS = 40_000
 # Dedicated loader waves of the flat tile kernel (round 3): the first L waves of a tile own no destination rows and issue the
 # whole global->LDS stream of the steady-state blocks; the other 16 - L waves only compute.  Used when a tile's rows fit the
 # remaining 16 x (16 - L) accumulator slots (cfg3's cell side: 195 rows per tile = 15 waves x 13 rows at L = 1; the gene side's
@@ -473,7 +500,7 @@ LOADER_MIN_ENTRIES = {1: 30.0, 2: 16.0, 3: 16.0}
 VIRTUAL_ROW_SHARE = 0.5   # few-row operands: a row heavier than this share of an average wave's load is dealt as virtual rows
 
 
-def _pair_segment_entries(seg: torch.Tensor, meta: torch.Tensor, val_bits: torch.Tensor, n_seg: int):
+def _pair_segment_entries(seg: torch.Tensor, meta: torch.Tensor, val_bits: torch.Tensor, n_seg: int, slot_mask: int = 0xF):
     """Entries of every (tile, block, wave) segment, ordered for the flat kernel's shared-pair stream.
 
     Two entries of a segment that read the SAME source row (one gene drawn by two of the wave's 16 cells; one cell
@@ -504,7 +531,7 @@ def _pair_segment_entries(seg: torch.Tensor, meta: torch.Tensor, val_bits: torch
     del gid, gstart, gsize, new_group
     # the second entry's slot rides in the first entry's word
     nxt_slot = torch.zeros_like(meta_s)
-    nxt_slot[:-1] = (meta_s[1:] >> 8) & 0xF
+    nxt_slot[:-1] = (meta_s[1:] >> 8) & slot_mask
     meta_s = torch.where(first, meta_s | (nxt_slot << 16), meta_s)
     del nxt_slot, first, idx_in
     perm2 = torch.sort(seg_s * 2 + shared.long(), stable=True).indices   # unshared first; pairs stay adjacent
@@ -544,10 +571,16 @@ class TilePlan:
     seg_ptr: Optional[torch.Tensor] = None     # int32 [n_tiles*nblk_max*16 + 1]
     nblk_max: int = 0
     block_rows: int = 64
+    geom: TileGeom = GEOM_FLAT
 
     @property
     def n_tiles(self) -> int:
         return self.items.shape[0]
+
+    @property
+    def block_rows_arg(self) -> int:
+        """The C ABI's ``block_rows`` argument: rows per LDS block | plan geometry bits (WGNN_PLAN_TALL)."""
+        return self.block_rows | (_lib.PLAN_TALL if self.geom.tall else 0)
 
 
 def _snake(p: torch.Tensor, n: int) -> torch.Tensor:
@@ -560,18 +593,19 @@ ONE_ROUND_MIN_NNZ = 0               # one round wins or ties at every size measu
 
 
 def auto_tile_geometry(n_rows: int, n_cols: int, n_cus: int = 256, nnz: Optional[int] = None,
-                       rows_cap: int = 256) -> Tuple[int, int]:
+                       rows_cap: int = 256, tile_rows: int = TILE_ROWS) -> Tuple[int, int]:
     """(n_row_tiles, n_col_splits), from sweeps at 10k..100k cells (profiles/r01_issue_analysis.md, r02_issue_analysis.md):
     * many rows (>= 40k): whole rounds of ~195..256-row tiles over the CUs, no column split;
     * fewer rows (the gene side; the cell side of small graphs): ~250-row tiles, and the source axis split so that
       hub rows spread over several workgroups and the launch has ~nnz/50k tiles (between 160 and five full rounds)."""
-    min_tiles = -(-n_rows // TILE_ROWS)
+    min_tiles = -(-n_rows // tile_rows)
     if n_rows >= 40_000:
         # `rows_cap` < 256 when dedicated loader waves are on: a tile's rows must fit the computing waves' accumulators
         # (cfg3: 447 -> 512 tiles either way; cfg5's 764,741 rows: 14 rounds of 213-row tiles instead of 12 of 249)
-        min_tiles = -(-n_rows // max(1, min(TILE_ROWS, rows_cap)))
+        min_tiles = -(-n_rows // max(1, min(tile_rows, rows_cap)))
         return -(-min_tiles // n_cus) * n_cus, 1
-    n_row_tiles = max(1, -(-n_rows // 250))
+    full = tile_rows * 250 // 256                         # ~98 % of a tile: 250 of 256 rows, 390 of 400
+    n_row_tiles = max(1, -(-n_rows // full))
     if nnz is not None and nnz >= ONE_ROUND_MIN_NNZ and n_row_tiles <= n_cus:
         # big operands: ONE round of <= n_cus workgroups.  Every extra column split costs one more partial-sum row per
         # destination row (written, then re-read by agg_finalize); at cfg3 the genes<-cells pass went from 80 x 16
@@ -581,8 +615,8 @@ def auto_tile_geometry(n_rows: int, n_cols: int, n_cus: int = 256, nnz: Optional
             sp = max(1, min(n_cus // rt, n_cols // 512 or 1))
             # fill the round with slightly smaller row tiles (82 -> 85 x 3 = 255 tiles), never by shredding a small operand
             return max(rt, min(n_cus // sp, -(-rt * 115 // 100))), sp
-        plain = one_round(250)
-        if rows_cap < 250:
+        plain = one_round(full)
+        if rows_cap < full:
             # tiles that leave room for loader waves (<= rows_cap rows) - taken when they still fill the round (a 12.5k-row
             # shard: 64 x 4 = 256 tiles of 195 rows instead of 51 x 5 of 245; cfg3's gene side would drop to 105 x 2 = 210
             # tiles of 21 % more work each and keeps 85 x 3)
@@ -620,7 +654,8 @@ def _flat_tile_index(n_col_splits: int, n_row_tiles: int, dev) -> torch.Tensor:
 
 
 def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits: Optional[int] = 1,
-                    n_cus: int = 256, block_rows: int = 64, balance: bool = True, n_loaders: int = 0) -> TilePlan:
+                    n_cus: int = 256, block_rows: int = 64, balance: bool = True, n_loaders: int = 0,
+                    geom: TileGeom = GEOM_FLAT) -> TilePlan:
     """Group the rows of ``csr`` into tiles of <= 256 rows (nnz-balanced across tiles and across the 16
     waves of a tile) and optionally split the column (source) range so hub rows spread over several
     workgroups.  Pure index arithmetic on the device; runs once per graph.
@@ -630,8 +665,12 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
     source block - that land in different waves (and tiles); each writes a partial sum that ``agg_finalize`` folds in
     fixed order, exactly like the partial sums of column splits.
 
-    ``n_col_splits=None``: heuristic geometry (``auto_tile_geometry`` on the number of virtual rows)."""
+    ``n_col_splits=None``: heuristic geometry (``auto_tile_geometry`` on the number of virtual rows).
+    ``geom``: GEOM_FLAT (16 waves x 16 rows) or GEOM_TALL (8 waves x 49 rows, no dedicated loader waves)."""
     dev = csr.device
+    TILE_ROWS, TILE_WAVES = geom.rows, geom.waves         # (shadow the module constants: everything below is per geometry)
+    if geom.tall:
+        n_loaders = 0                                     # 8 waves: none to spare, every wave streams its share
     R, S = csr.n_rows, csr.n_cols
     nnz = (csr.rowptr[1:] - csr.rowptr[:-1]).long()
     total = int(nnz.sum())
@@ -664,7 +703,7 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
         V = int(vbase[-1])                                                  # number of virtual rows
         min_tiles = -(-V // TILE_ROWS)
         if auto_geom:
-            n_row_tiles, n_col_splits = auto_tile_geometry(V, S, n_cus, total, rpw * (TILE_WAVES - n_loaders))
+            n_row_tiles, n_col_splits = auto_tile_geometry(V, S, n_cus, total, rpw * (TILE_WAVES - n_loaders), TILE_ROWS)
         if not few_rows or last or n_loaders == 0:
             break
         rt = max(n_row_tiles if n_row_tiles is not None else 0, min_tiles, 1)
@@ -760,7 +799,7 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
         entries = torch.stack([meta[perm], val_bits[perm]], 1).contiguous()
         del perm, meta
     else:
-        entries, seg_ptr = _pair_segment_entries(key, meta, val_bits, n_seg)
+        entries, seg_ptr = _pair_segment_entries(key, meta, val_bits, n_seg, 0x3F if geom.tall else 0xF)
         del key, meta, virt
     return TilePlan(items.contiguous(), hdr.contiguous(), long_rows, n_part,
-                    n_row_tiles, n_col_splits, n_loaders, entries, seg_ptr.to(torch.int32), nblk_max, block_rows)
+                    n_row_tiles, n_col_splits, n_loaders, entries, seg_ptr.to(torch.int32), nblk_max, block_rows, geom)

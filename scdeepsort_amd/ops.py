@@ -200,7 +200,7 @@ def agg_bwd_src(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, g: torch.
         rc = _lib.call(dev, "wgnn_agg_bwd_src_tiled",
             _ptr(alpha), mode, _ptr(scale), _ptr(g), g.shape[0], _ptr(scratch),
             _ptr(h_src), h_src.stride(0) if h_src is not None else 0, _ptr(dh_src), dh_src.stride(0), _ptr(dalpha),
-            int(accumulate), t.n_rows, D, _ptr(tp.entries), _ptr(tp.seg_ptr), tp.nblk_max, tp.block_rows,
+            int(accumulate), t.n_rows, D, _ptr(tp.entries), _ptr(tp.seg_ptr), tp.nblk_max, tp.block_rows_arg,
             _ptr(tp.items), _ptr(tp.hdr), tp.n_tiles, _ptr(tp.long_rows) if n_long else None, n_long,
             _ptr(part), tp.n_partials, _stream(dev))
         _lib.check(rc, "wgnn_agg_bwd_src_tiled")
@@ -269,7 +269,7 @@ def agg_bwd_alpha(csr: AggCsr, g: torch.Tensor, h_src: torch.Tensor, h_self: Opt
         rc = _lib.call(dev, "wgnn_agg_bwd_alpha_tiled",
             _ptr(csr.inv_deg), _ptr(g), g.stride(0), _ptr(h_src), _ptr(h_self),
             h_self.stride(0) if h_self is not None else 0, _ptr(d_row), _ptr(d_self), n_out, D,
-            _ptr(tp.entries), _ptr(tp.seg_ptr), tp.nblk_max, tp.block_rows, _ptr(tp.items), _ptr(tp.hdr), tp.n_tiles,
+            _ptr(tp.entries), _ptr(tp.seg_ptr), tp.nblk_max, tp.block_rows_arg, _ptr(tp.items), _ptr(tp.hdr), tp.n_tiles,
             _ptr(tp.long_rows) if n_long else None, n_long, _ptr(part), tp.n_partials, _stream(dev))
         _lib.check(rc, "wgnn_agg_bwd_alpha_tiled")
         return d_row, d_self
@@ -427,13 +427,13 @@ def agg_fwd_tiled(csr: AggCsr, tplan, alpha: Optional[torch.Tensor], mode: int, 
         _ptr(csr.rowptr), _ptr(alpha), mode, self_idx,
         _ptr(h_src), h_src.shape[0], _ptr(scratch), _ptr(h_self), h_self.stride(0) if h_self is not None else 0,
         None, _ptr(csr.inv_deg), _ptr(bias), _ptr(out), out.stride(0), _ptr(neigh_sum), csr.n_rows, D, flags,
-        _ptr(tplan.entries), _ptr(tplan.seg_ptr), tplan.nblk_max, tplan.block_rows, _ptr(tplan.items), _ptr(tplan.hdr), tplan.n_tiles,
+        _ptr(tplan.entries), _ptr(tplan.seg_ptr), tplan.nblk_max, tplan.block_rows_arg, _ptr(tplan.items), _ptr(tplan.hdr), tplan.n_tiles,
         _ptr(tplan.long_rows) if n_long else None, n_long, _ptr(part), tplan.n_partials, _stream(dev))
     _lib.check(rc, "wgnn_agg_fwd_tiled")
     if ev is not None:
         ev[1].record(torch.cuda.current_stream(dev))
         PROFILE.append((("rows", csr.n_rows, "cols", csr.n_cols, "nnz", csr.nnz, "D", D, "mode", mode,
-                         "kernel", "agg_tiled_flat4"), ev[0], ev[1]))
+                         "kernel", "agg_tiled_tall" if tplan.geom.tall else "agg_tiled_flat4"), ev[0], ev[1]))
     return out
 
 

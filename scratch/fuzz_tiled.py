@@ -27,11 +27,13 @@ for it in range(int(sys.argv[2]) if len(sys.argv)>2 else 60):
         rt=int(rng.integers(1,8)); cs=int(rng.integers(1,6))
         GR.TILE_SHARED_PAIRS = bool(rng.random() < 0.8)               # shared pairs (round 3) on most draws
         L = int(rng.choice([0, 0, 1, 2, 3]))                          # dedicated loader waves (falls back to 0 if the tile is too tall)
-        tp=build_tile_plan(csr, None if rng.random()<0.3 else max(rt,-(-csr.n_rows//256)), cs, block_rows=kb, n_loaders=L)
+        tall = bool(rng.random() < 0.5) and GR.TILE_SHARED_PAIRS            # round 5: the tall tile geometry (8 waves x 50 rows)
+        geom = GR.GEOM_TALL if tall else GR.GEOM_FLAT
+        tp=build_tile_plan(csr, None if rng.random()<0.3 else max(rt,-(-csr.n_rows//geom.rows)), cs, block_rows=kb, n_loaders=L, geom=geom)
         kw=dict(out_scale_alpha=True) if (osa and mode==sda.DST_IS_GENE) else {}
         ref=ops.agg_fwd(csr,alpha,mode,si,hs,hself,**kw)
         out=ops.agg_fwd_tiled(csr,tp,alpha,mode,si,hs,hself,**kw)
         err=float((ref-out).abs().max()); worst=max(worst,err)
         if not err < 1e-4:
-            print('MISMATCH',it,C,G,dens,D,kb,rt,cs,L,GR.TILE_SHARED_PAIRS,err); sys.exit(1)
+            print('MISMATCH',it,C,G,dens,D,kb,rt,cs,L,GR.TILE_SHARED_PAIRS,tall,err); sys.exit(1)
 print('fuzz ok, worst abs diff', worst)

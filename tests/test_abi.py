@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in wgnn.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in _lib.py"
-    assert lib.wgnn_version() == 203 and lib.wgnn_version() >= _lib.ABI_MIN
+    assert lib.wgnn_version() == 204 and lib.wgnn_version() >= _lib.ABI_MIN
     assert b"ok" == lib.wgnn_last_error_string(0)
 
 
@@ -176,11 +176,14 @@ def test_flat4_register_contract_is_enforced_at_build_time():
     regions) names v32..v127 - round 3's build parked 3-20 spilled SGPRs in a VGPR of the hand-owned file."""
     from scdeepsort_amd import build as B
     usage = B.flat4_resource_usage()
-    assert len(usage) == 6 and all("agg_tiled_flat4" in k for k in usage)           # 3 epilogues x {production, ablation}
+    # 3 epilogues x {production, ablation}, for each of the two tile geometries (round 5: agg_tiled_tall - 8 waves x 256 VGPRs,
+    # the compiler capped at v[0:41], v[42:255] carry state across statements)
+    assert len(usage) == 12 and sum("agg_tiled_flat4" in k for k in usage) == 6 and sum("agg_tiled_tall" in k for k in usage) == 6
     for name, rec in usage.items():
         rm, md = rec["remarks"], rec["metadata"]
-        assert rm["VGPRs"] == "128" and rm["ScratchSize"] == "0", (name, rm)
-        assert rm["SGPRs Spill"] == "0" and rm["VGPRs Spill"] == "0" and rm["Occupancy"] == "4", (name, rm)
+        tall = "agg_tiled_tall" in name
+        assert rm["VGPRs"] == ("256" if tall else "128") and rm["ScratchSize"] == "0", (name, rm)
+        assert rm["SGPRs Spill"] == "0" and rm["VGPRs Spill"] == "0" and rm["Occupancy"] == ("2" if tall else "4"), (name, rm)
         assert md["sgpr_spill_count"] == 0 and md["vgpr_spill_count"] == 0 and md["private_segment_fixed_size"] == 0, (name, md)
         assert rec["compiler_touches_hand_registers"] == [], (name, rec["compiler_touches_hand_registers"][:5])
     B.audit_flat4(usage)
@@ -206,4 +209,8 @@ def test_hand_written_statements_name_every_owned_register():
     assert [f'"s{i}"' for i in range(80, 96)] == [t.strip() for t in sl.split("WGNN_HAND_SGPRS", 1)[1].split(",")]
     src = (ROOT / "scdeepsort_amd" / "csrc" / "wgnn_tiled.hip").read_text()
     assert '#define WGNN_CLOB "m0", "memory", "scc", WGNN_HAND_VGPRS, WGNN_HAND_SGPRS' in src
+    tl = next(l for l in inc.splitlines() if l.startswith("#define WGNN_TALL_VGPRS"))
+    assert [f'"v{i}"' for i in range(20, 256)] == [t.strip() for t in tl.split("WGNN_TALL_VGPRS", 1)[1].split(",")]
+    assert '#define WGNN_TALL_CLOB "m0", "memory", "scc", WGNN_TALL_VGPRS, WGNN_HAND_SGPRS' in src
+    assert "__attribute__((amdgpu_num_vgpr(21)))" in src          # the tall kernel: compiler v[0:41]
     assert "__attribute__((amdgpu_num_vgpr(16)))" in src and "amdgpu_num_sgpr" not in src.split("agg_tiled_flat4(const KArgs")[0][-300:]

@@ -1743,6 +1743,68 @@ def test_tile_kernel_dedicated_loader_waves(kb, D, direction):
     np.testing.assert_allclose(run(crowded).cpu().numpy(), want, atol=TOL)
 
 
+@pytest.mark.parametrize("D", [64, 200, 256])
+def test_tall_tile_kernel_matches_the_oracle_and_the_flat_kernel(D):
+    """Round 5: agg_tiled_tall - the entry pipeline on 8 waves x 256 VGPRs, 49 destination rows per wave (`graph.GEOM_TALL`,
+    plan bit WGNN_PLAN_TALL; opt-in through `graph.TILE_TALL`, see there for why).  Forward in both directions with explicit and
+    heuristic geometries, column splits, several LDS block heights incl. segments of more than four chunks (the on-demand chunk
+    path), D = 200 (global rows shorter than their LDS slots: the one-piece DMA form) - against the oracle; and the backward
+    entries K2t / K3t with TILE_TALL = "on" against the row-wave kernels."""
+    from scdeepsort_amd.graph import build_tile_plan
+    from scdeepsort_amd import ops, graph as GR
+    c = small_case(cells=1900, genes=420, dim=D, seed=D + 5, density=0.3, test_cells=40)
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
+    cgo = O.build_csr_graph(c["expr"], c["support_mask"])
+    G = c["G"]; rng = np.random.default_rng(D)
+    alpha = dev(rng.uniform(0.5, 1.5, G + 2).astype(np.float32))
+    Hg, Hc = c["feats"][:G], c["feats"][G:]
+    zc, zg = O.csr_aggregate(cgo, alpha.cpu().numpy(), Hg.astype(np.float64), Hc.astype(np.float64))
+    for csr, mode, sidx, src, slf, want in ((g.cg, sda.SRC_IS_GENE, G + 1, dev(Hg), dev(Hc), zc),
+                                            (g.gc, sda.DST_IS_GENE, G, dev(Hc), dev(Hg), zg)):
+        for rt, cs, kb in ((None, None, 78), (-(-csr.n_rows // 392), 1, 78), (7, 2, 23), (5, 3, 64)):
+            if kb > ops.tiled_block_rows(D):
+                kb = ops.tiled_block_rows(D)
+            tp = build_tile_plan(csr, rt, cs, block_rows=kb, geom=GR.GEOM_TALL)
+            assert tp.geom.tall and tp.items.shape[1] == 392 and tp.n_loaders == 0
+            seg = tp.seg_ptr.long()
+            if rt is not None and cs == 1 and kb >= 64:
+                assert int((seg[1:] - seg[:-1]).max()) > 256                      # more than four chunks in one (wave, block)
+            out = ops.agg_fwd_tiled(csr, tp, alpha, mode, sidx, src, slf)
+            np.testing.assert_allclose(out.cpu().numpy(), want, atol=TOL, rtol=1e-5)
+            assert torch.equal(ops.agg_fwd_tiled(csr, tp, alpha, mode, sidx, src, slf), out)      # deterministic
+            flat = ops.agg_fwd_tiled(csr, build_tile_plan(csr, None, None, block_rows=kb, n_loaders=1), alpha, mode, sidx, src, slf)
+            np.testing.assert_allclose(out.cpu().numpy(), flat.cpu().numpy(), atol=2e-5, rtol=1e-5)
+    # backward entries over tall plans (dispatch forced to the tile kernels, TILE_TALL = "on") against the row-wave kernels
+    gen = torch.Generator(device=DEV).manual_seed(D)
+    gc_ = torch.randn(g.cg.n_rows, D, generator=gen, device=DEV); gg_ = torch.randn(g.gc.n_rows, D, generator=gen, device=DEV)
+    hg_, hc_ = dev(Hg), dev(Hc)
+    def grads():
+        da = torch.zeros(G + 2, device=DEV)
+        dh_g = ops.agg_bwd_src(g.cg, alpha, sda.SRC_IS_GENE, gc_, hg_, dalpha=da)
+        dh_c = ops.agg_bwd_src(g.gc, alpha, sda.DST_IS_GENE, gg_, hc_)
+        k3 = ops.agg_bwd_alpha(g.gc, gg_, hc_, hg_)
+        return [dh_g, dh_c, da] + [t for t in k3 if t is not None]
+    saved = (ops.TILED_MIN_WORK, GR.TILE_TALL)
+    try:
+        ops.TILED_MIN_WORK = None
+        ref = grads()
+        ops.TILED_MIN_WORK, GR.TILE_TALL = 0, "on"
+        for csr in (g.cg, g.gc):
+            csr._tile_plan = None
+            if csr._t is not None:
+                csr._t._tile_plan = None
+        got = grads()
+        assert g.cg.transposed().tile_plan(ops.tiled_block_rows(D)).geom.tall
+    finally:
+        ops.TILED_MIN_WORK, GR.TILE_TALL = saved
+        for csr in (g.cg, g.gc):
+            csr._tile_plan = None
+            if csr._t is not None:
+                csr._t._tile_plan = None
+    for a_, b_ in zip(got, ref):
+        np.testing.assert_allclose(a_.cpu().numpy(), b_.cpu().numpy(), atol=2e-4 * max(1.0, float(b_.abs().max())), rtol=1e-4)
+
+
 @pytest.mark.parametrize("density", [0.01, 0.08, 0.5, 0.95])
 @pytest.mark.parametrize("D", [64, 256])
 def test_tile_kernel_shared_pairs(density, D):

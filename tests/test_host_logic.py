@@ -294,6 +294,62 @@ def test_tile_plan_with_loader_waves_covers_every_edge_once():
     assert crowded.n_loaders == 0
 
 
+def test_tall_tile_plan_covers_every_edge_once():
+    """Round 5: the TALL tile geometry (8 waves x 49 rows, `graph.GEOM_TALL`, kernel agg_tiled_tall).  Same plan builder, other
+    constants: 392 item slots per tile, 8 segments per (tile, block), 6-bit slot fields, no dedicated loader wave; the
+    re-ordered entries hold every non-zero exactly once, shared pairs close their segment.  `graph.TILE_TALL = "auto"` picks it for
+    many-row operands (>= 40 000 rows) and sizes ONE round of <= 392-row tiles where that covers the rows."""
+    import scipy.sparse as sp
+    from scdeepsort_amd import graph as GR, _lib
+    X = sp.random(2100, 500, density=0.07, format="csr", random_state=7, dtype=np.float32)
+    X.data = np.abs(X.data) + 0.5
+    Xd = X.toarray(); Xd[:, 5] = 1.5
+    X = sp.csr_matrix(Xd)
+    for A, geoms in ((X, [(6, 1), (None, None), (7, 2)]), (sp.csr_matrix(X.T), [(2, 3), (None, None)])):
+        csr = _cpu_agg_csr(A)
+        want = sorted(zip(np.repeat(np.arange(A.shape[0]), np.diff(sp.csr_matrix(A).indptr)).tolist(),
+                          csr.col.tolist(), csr.val.tolist()))
+        for rt, cs in geoms:
+            tp = GR.build_tile_plan(csr, rt, cs, block_rows=40, n_loaders=1, geom=GR.GEOM_TALL)
+            assert tp.geom.tall and tp.n_loaders == 0 and tp.items.shape[1] == 392
+            assert tp.block_rows_arg == 40 | _lib.PLAN_TALL
+            slots = tp.items[:, :, 0].reshape(tp.n_tiles, 8, 49)
+            filled = slots >= 0
+            assert not (filled[:, :, 1:] & ~filled[:, :, :-1]).any()
+            seg = tp.seg_ptr.long()
+            n_seg = seg.shape[0] - 1
+            assert n_seg == tp.n_tiles * tp.nblk_max * 8
+            per = seg[1:] - seg[:-1]
+            sid = torch.repeat_interleave(torch.arange(n_seg), per)
+            wave, blk, tile = sid % 8, (sid // 8) % tp.nblk_max, sid // (8 * tp.nblk_max)
+            meta, wbits = tp.entries[:, 0].long(), tp.entries[:, 1]
+            dslot, src_local = (meta >> 8) & 0x3F, meta & 0xFF
+            paired, padded = meta < 0, (meta & GR.TILE_PAD_FLAG) != 0
+            off = torch.arange(meta.shape[0]) - seg[sid]
+            first = torch.nonzero(paired & (off % 2 == 0)).squeeze(1)
+            assert first.numel() * 2 == int(paired.sum()) and paired.any()
+            assert (src_local[first + 1] == src_local[first]).all() and (((meta[first] >> 16) & 0x3F) == dslot[first + 1]).all()
+            n_pair = torch.bincount(sid[paired], minlength=n_seg)
+            assert (paired == (off >= (per - n_pair)[sid])).all() and ((per - n_pair)[n_pair > 0] % 2 == 0).all()
+            keep = ~padded
+            row = slots[tile, wave, dslot].long()
+            col = tp.hdr[tile, 0].long() + blk * tp.block_rows + src_local
+            got = sorted(zip(row[keep].tolist(), col[keep].tolist(), wbits[keep].view(torch.float32).tolist()))
+            assert got == want, (rt, cs)
+    # heuristics: 100 000 rows -> one round of 256 tiles (391 rows each); 764 741 rows -> whole rounds of <= 392-row tiles
+    assert GR.auto_tile_geometry(100_000, 20_000, 256, 80_000_000, 392, 392) == (256, 1)
+    rt, sp_ = GR.auto_tile_geometry(764_741, 20_000, 256, 612_000_000, 392, 392)
+    assert sp_ == 1 and rt % 256 == 0 and -(-764_741 // rt) <= 392
+    big = _cpu_agg_csr(sp.csr_matrix((np.ones(1, np.float32), ([0], [0])), shape=(GR.TALL_MIN_ROWS, 8)))
+    assert GR.TILE_TALL == "off" and not big.tile_plan(16).geom.tall          # opt-in (measured slower at cfg3, see graph.TILE_TALL)
+    saved, GR.TILE_TALL = GR.TILE_TALL, "auto"
+    try:
+        big._tile_plan = None
+        assert big.tile_plan(16).geom.tall and not _cpu_agg_csr(X).tile_plan(16).geom.tall
+    finally:
+        GR.TILE_TALL = saved
+
+
 def test_device_built_plan_cuts_only_hub_rows():
     """the static-shape plan of a device-built (transposed / sampled) block gives every row ONE item and cuts only
     the rows longer than the chunk, into <= 8 parts on a fixed number of hub slots (unused slots = items with row -1, which
@@ -334,6 +390,26 @@ def test_device_built_plan_cuts_only_hub_rows():
     rp = torch.tensor([0, 5, 5, 40], dtype=torch.int32)
     q = device_plan(rp, 3, 40, 16)
     assert q.items.shape[0] == 3 * 3 and q.n_partials == 9
+
+
+def test_bench_workload_string_does_not_depend_on_the_rank_count():
+    """the N = 1 leg of a SCALE run must name the same workload as the BENCH line.  `config.workload` is a
+    pure function of the config and the scaling mode (bench.workload_string), the default mode is strong at every N, and the
+    default config is BASELINE cfg3."""
+    import importlib.util
+    import inspect
+    from pathlib import Path
+    from scdeepsort_amd import synthetic as S
+    spec = importlib.util.spec_from_file_location("bench_mod", Path(sda.__file__).resolve().parent.parent / "bench.py")
+    bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+    assert list(inspect.signature(bench.workload_string).parameters) == ["cfg", "total_cells", "mode"]     # no world / rank argument
+    cfg = S.CONFIGS["cfg3"]
+    w = bench.workload_string(cfg, cfg.cells, "strong")
+    assert w == ("cfg3: 100000 cells x 20000 genes (ONE job, cells sharded over the ranks), density 0.04, dense_dim 400, "
+                 "hidden 256, 2-layer WGNN forward + 16-class head")
+    src = Path(bench.__file__).read_text()
+    assert '"workload": workload_string(cfg, total_cells, mode)' in src
+    assert 'default=os.environ.get("WGNN_BENCH_CONFIG", "cfg3")' in src and 'default=os.environ.get("WGNN_BENCH_SCALING", "strong")' in src
 
 
 def test_tracked_gemm_picks_file_is_wellformed():
