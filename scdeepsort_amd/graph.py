@@ -220,7 +220,7 @@ class AggCsr:
             torch.cumsum(counts, 0, out=t_rowptr[1:])
             rows = torch.repeat_interleave(torch.arange(self.n_rows, device=dev, dtype=torch.int32),
                                            (self.rowptr[1:] - self.rowptr[:-1]).long())
-            order = torch.sort(self.col.long(), stable=True).indices
+            order = torch.sort(self.col, stable=True).indices               # int32 keys
             t_col = rows[order].contiguous()
             t_val = self.val[order].contiguous()
             t_rowptr32 = t_rowptr.to(torch.int32)
@@ -405,7 +405,7 @@ class CellGeneGraph:
         counts = torch.bincount(s_col.long(), minlength=num_genes)
         t_rowptr = torch.zeros(num_genes + 1, dtype=torch.int64, device=dev)
         torch.cumsum(counts, 0, out=t_rowptr[1:])
-        order = torch.sort(s_col.long(), stable=True).indices
+        order = torch.sort(s_col, stable=True).indices          # 32-bit keys: half the radix passes of .long()
         t_col = rows[order].contiguous()
         t_raw = s_raw[order].contiguous()
         del rows, order
@@ -513,44 +513,67 @@ def _pair_segment_entries(seg: torch.Tensor, meta: torch.Tensor, val_bits: torch
     Returns (entries int32 [n, 2], seg_ptr int64 [n_seg + 1])."""
     dev = seg.device
     n = seg.shape[0]
-    meta = meta.long()
-    perm = torch.sort(seg * 256 + (meta & 0xFF), stable=True).indices   # group by (segment, source row), CSR order inside
-    seg_s, meta_s, val_s = seg[perm], meta[perm], val_bits[perm]
+    # Round 5: ONE sort instead of two, on 32-bit keys where they fit (a 64-bit stable sort of 8e7 keys is most of a plan's build
+    # time).  The second sort ("unshared first, pairs stay adjacent") is replaced by arithmetic: an entry's position inside its
+    # segment is the number of unshared (or shared) entries in front of it in (segment, source row) order - two running sums.
+    small = n_seg * 256 < 2 ** 31 - 1
+    kdt = torch.int32 if small else torch.int64
+    src_local = (meta & 0xFF).to(kdt)
+    key1 = seg.to(kdt) * 256 + src_local
+    del src_local
+    perm = torch.sort(key1, stable=True).indices        # group by (segment, source row), CSR order inside
+    gkey = key1[perm]
+    del key1
+    meta_s, val_s = meta.to(torch.int32)[perm], val_bits[perm]
     del perm
-    gkey = seg_s * 256 + (meta_s & 0xFF)
-    ar = torch.arange(n, device=dev)
+    seg_s = torch.div(gkey, 256, rounding_mode="floor")
+    idt = torch.int32 if n < 2 ** 31 - 1 else torch.int64
+    ar = torch.arange(n, device=dev, dtype=idt)
     new_group = torch.ones(n, dtype=torch.bool, device=dev)
     new_group[1:] = gkey[1:] != gkey[:-1]
     del gkey
-    gid = torch.cumsum(new_group, 0) - 1
+    gid = torch.cumsum(new_group, 0, dtype=idt) - 1
     gstart = ar[new_group]
-    gsize = torch.diff(gstart, append=torch.tensor([n], device=dev))
+    gsize = torch.diff(gstart, append=torch.tensor([n], device=dev, dtype=idt))
     idx_in = ar - gstart[gid]
     shared = idx_in < (gsize[gid] // 2) * 2
     first = shared & (idx_in % 2 == 0)
-    del gid, gstart, gsize, new_group
+    del gid, gstart, gsize, new_group, idx_in
     # the second entry's slot rides in the first entry's word
     nxt_slot = torch.zeros_like(meta_s)
     nxt_slot[:-1] = (meta_s[1:] >> 8) & slot_mask
     meta_s = torch.where(first, meta_s | (nxt_slot << 16), meta_s)
-    del nxt_slot, first, idx_in
-    perm2 = torch.sort(seg_s * 2 + shared.long(), stable=True).indices   # unshared first; pairs stay adjacent
-    seg_s, meta_s, val_s, shared = seg_s[perm2], meta_s[perm2], val_s[perm2], shared[perm2]
-    del perm2
-    n_all = torch.bincount(seg_s, minlength=n_seg)
-    n_sh = torch.bincount(seg_s[shared], minlength=n_seg)
+    del nxt_slot, first
+    meta_s = torch.where(shared, meta_s | torch.tensor(TILE_PAIR_FLAG, dtype=torch.int32, device=dev), meta_s)
+    # per-segment counts WITHOUT a histogram (an atomic histogram of 8e7 keys costs 3.5 ms, twice): the entries are sorted by
+    # segment, so a segment is the index range between two binary searches, and its number of shared entries is a difference of
+    # the running sum below
+    bounds = torch.searchsorted(seg_s, torch.arange(n_seg + 1, device=dev, dtype=seg_s.dtype))          # int64 [n_seg + 1]
+    n_all = bounds[1:] - bounds[:-1]
+    sh = shared.to(idt)
+    cs_sh = torch.zeros(n + 1, dtype=idt, device=dev)
+    torch.cumsum(sh, 0, out=cs_sh[1:])                                    # cs_sh[i] = shared entries among the first i
+    del sh
+    base_sh = cs_sh[bounds[:-1]].long()
+    n_sh = cs_sh[bounds[1:]].long() - base_sh
     pad = ((n_all - n_sh) & 1) * (n_sh > 0).long()                        # only where pairs follow the unshared run
-    old_ptr = torch.zeros(n_seg + 1, dtype=torch.int64, device=dev)
-    torch.cumsum(n_all, 0, out=old_ptr[1:])
     seg_ptr = torch.zeros(n_seg + 1, dtype=torch.int64, device=dev)
     torch.cumsum(n_all + pad, 0, out=seg_ptr[1:])
-    pos = seg_ptr[seg_s] + (ar - old_ptr[seg_s]) + torch.where(shared, pad[seg_s], torch.zeros_like(seg_s))
+    # position = seg_ptr[s] + (unshared: entries of s in front of me that are unshared | shared: all unshared of s + pad + shared
+    # ones in front of me), folded into ONE per-segment offset for either kind (two gathers by segment instead of four):
+    #   shared   : A[s] + c      A = seg_ptr + n_unshared + pad - base_sh      (c = shared entries among ALL entries in front of me)
+    #   unshared : B[s] + i - c  B = seg_ptr - bounds + base_sh                (i = my index in sorted order)
+    A = seg_ptr[:-1] + (n_all - n_sh + pad) - base_sh
+    B = seg_ptr[:-1] - bounds[:-1] + base_sh
+    seg_l = seg_s.long()
+    c = cs_sh[:-1].long()
+    del cs_sh
+    pos = torch.where(shared, A[seg_l] + c, B[seg_l] + (ar.long() - c))
+    del c, seg_l, A, B
     total = int(seg_ptr[-1])
-    meta32 = meta_s.to(torch.int32)
-    meta32 = torch.where(shared, meta32 | torch.tensor(TILE_PAIR_FLAG, dtype=torch.int32, device=dev), meta32)
     entries = torch.zeros((total, 2), dtype=torch.int32, device=dev)
-    entries[pos, 0] = meta32
-    entries[pos, 1] = val_s
+    entries[pos] = torch.stack([meta_s, val_s], 1)                        # one 8-byte row scatter
+    del pos
     pseg = torch.nonzero(pad).squeeze(1)
     if pseg.numel():
         ppos = seg_ptr[pseg] + (n_all - n_sh)[pseg]                       # right behind the (odd number of) unshared entries
@@ -775,21 +798,37 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
     wave_v = torch.empty(V, dtype=torch.int64, device=dev); wave_v[order] = wave
     slot_v = torch.empty(V, dtype=torch.int64, device=dev); slot_v[order] = slot_in_wave
     nblk_max = max(1, per_split // blk)
-    rows_of = torch.repeat_interleave(torch.arange(R, device=dev), nnz)
-    pos = torch.arange(rows_of.shape[0], device=dev) - csr.rowptr.long()[rows_of]
-    virt = vbase[rows_of] + pos % k_r[rows_of]                             # the virtual row every non-zero belongs to
-    del pos, rows_of
-    colv = csr.col.long()
-    ksplit = torch.div(colv, per_split, rounding_mode="floor")
-    rel = colv - ksplit * per_split
-    key = (flat_of[ksplit, tile_v[virt]] * nblk_max + torch.div(rel, blk, rounding_mode="floor")) * TILE_WAVES \
-        + wave_v[virt]
-    meta = ((slot_v[virt] << 8) | (rel % blk)).to(torch.int32)
-    del ksplit, rel, colv
+    # (round 5: 32-bit index arithmetic and one gather per non-zero where the operand allows it - these are 8e7-element passes)
+    i32 = total < 2 ** 31 - 1 and n_col_splits * n_row_tiles * nblk_max * TILE_WAVES < 2 ** 31 - 1
+    it = torch.int32 if i32 else torch.int64
+    rows_of = torch.repeat_interleave(torch.arange(R, device=dev, dtype=it), nnz)
+    if few_rows:
+        pos = torch.arange(rows_of.shape[0], device=dev, dtype=it) - csr.rowptr.to(it)[rows_of]
+        virt = vbase.to(it)[rows_of] + pos % k_r.to(it)[rows_of]             # the virtual row every non-zero belongs to
+        del pos
+    else:
+        virt = rows_of                                                        # k_r == 1 everywhere: virtual row == row
+    del rows_of
+    colv = csr.col.to(it)
+    if n_col_splits == 1:
+        blk_of = torch.div(colv, blk, rounding_mode="floor")
+        src_local = colv - blk_of * blk
+        base_v = ((flat_of[0][tile_v] * nblk_max) * TILE_WAVES + wave_v).to(it)     # per virtual row: its segment at block 0
+        key = base_v[virt] + blk_of * TILE_WAVES
+        del blk_of, base_v
+    else:
+        ksplit = torch.div(colv, per_split, rounding_mode="floor")
+        rel = colv - ksplit * per_split
+        src_local = rel % blk
+        key = ((flat_of.to(it)[ksplit.long(), tile_v[virt]] * nblk_max + torch.div(rel, blk, rounding_mode="floor")) * TILE_WAVES
+               + wave_v.to(it)[virt])
+        del ksplit, rel
+    meta = ((slot_v.to(torch.int32)[virt] << 8) | src_local.to(torch.int32))
+    del colv, src_local
     n_seg = n_col_splits * n_row_tiles * nblk_max * TILE_WAVES
     val_bits = csr.val.view(torch.int32)
     if not TILE_SHARED_PAIRS:
-        key = key * (TILE_ROWS // TILE_WAVES) + slot_v[virt]
+        key = key.long() * (TILE_ROWS // TILE_WAVES) + slot_v[virt]
         del virt
         perm = torch.sort(key, stable=True).indices
         counts = torch.bincount(torch.div(key, TILE_ROWS // TILE_WAVES, rounding_mode="floor"), minlength=n_seg)

@@ -2280,6 +2280,64 @@ def test_full_size_cfg5_sharded_eight_ways_matches_unsharded():
     assert worst < 1e-4, worst
 
 
+def test_fallen_back_dense_paths_give_the_same_results(monkeypatch):
+    """the stack-coupled fast paths of the dense half - `torch._addmm_activation` (a private entry point: bias
+    + ReLU in the GEMM epilogue, no-grad and training), the tracked TunableOp picks (not loaded in this process), hipBLASLt as
+    preferred BLAS - each fall back to a plain composition.  Here the fallen-back state is EXERCISED where it would be used: the
+    forward and a training step with `_addmm_activation` absent and with it raising, against the same model with it present
+    and against the oracle."""
+    from scdeepsort_amd import ops, tuning
+    assert not tuning.active()                                  # this process never loaded the picks: library heuristics
+    c = small_case(cells=900, genes=300, dim=48, hidden=32, seed=77, density=0.12, test_cells=0)
+    g = sda.CellGeneGraph.from_expression(c["expr"], device=DEV)
+    sd = O.init_params(48, 32, 5, 2, c["G"], seed=3)
+    want = O.csr_forward(sd, O.build_csr_graph(c["expr"]), c["feats"], 2)
+    feats = dev(c["feats"])
+    labels = (torch.arange(900, device=DEV) * 7 % 5).long()
+
+    def run():
+        m = sda.GNN(48, 32, 5, 2, c["G"], activation=F.relu).to(DEV)
+        m.load_state_dict(sd)
+        m.order = "aggregate_first"                             # the order whose Linear + bias + ReLU uses the fused epilogue
+        m.eval()
+        with torch.no_grad():
+            logits = m(g, feats)
+        m.train()
+        loss = ops.cross_entropy_sum(m(g, feats), labels)
+        loss.backward()
+        return logits, loss.detach(), {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    base = run()
+    assert hasattr(torch, "_addmm_activation")
+    real = torch._addmm_activation
+    calls = {"n": 0}
+
+    def raising(*a, **k):
+        calls["n"] += 1
+        raise RuntimeError("contract changed")
+    monkeypatch.setattr(torch, "_addmm_activation", raising)
+    raised = run()
+    assert calls["n"] > 0                                        # the fast path WAS attempted and fell back
+    monkeypatch.delattr(torch, "_addmm_activation")
+    absent = run()
+    monkeypatch.setattr(torch, "_addmm_activation", real, raising=False)
+    for other in (raised, absent):
+        np.testing.assert_allclose(other[0].cpu().numpy(), base[0].cpu().numpy(), atol=2e-6, rtol=1e-6)
+        assert abs(float(other[1]) - float(base[1])) < 1e-5 * max(1.0, abs(float(base[1])))
+        for k in base[2]:
+            np.testing.assert_allclose(other[2][k].cpu().numpy(), base[2][k].cpu().numpy(), atol=2e-5, rtol=1e-4, err_msg=k)
+    np.testing.assert_allclose(base[0].cpu().numpy(), want, atol=TOL)
+    np.testing.assert_allclose(absent[0].cpu().numpy(), want, atol=TOL)
+    # the preferred-BLAS switch of bench.py is a hint with a fallback of its own: either answer leaves the results alone
+    try:
+        torch.backends.cuda.preferred_blas_library("hipblaslt")
+        with_lt = run()[0]
+        torch.backends.cuda.preferred_blas_library("default")
+        np.testing.assert_allclose(with_lt.cpu().numpy(), base[0].cpu().numpy(), atol=2e-6, rtol=1e-6)
+    except Exception:
+        pass
+
+
 def test_tuned_gemm_picks_change_speed_not_results():
     """`tuning.use_tuned_gemms()` (PyTorch TunableOp, selection only) routes the dense projections to the library kernels
     recorded per shape in the tracked file: same logits to rounding, and the fp32 projections leave wgnn_linear_fwd for
