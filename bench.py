@@ -569,9 +569,39 @@ def main():
         for _ in range(n_tr):
             tl = tstep()
         torch.cuda.synchronize()
-        train_step = {"ms_per_step": round((time.perf_counter() - t0) / n_tr * 1e3, 4), "steps": n_tr, "loss": round(float(tl), 2),
+        t_train = (time.perf_counter() - t0) / n_tr * 1e3
+        # per-kernel roofline entries of the step (HIP events on the launch stream, a separate profiled pass of 3 steps):
+        # the aggregation passes against the HBM roofline (the same algorithmic-bytes formula on the operand each launch walks),
+        # the matrix-core weight gradients against the fp32 matrix peak
+        from scdeepsort_amd import ops as _ops
+        _ops.PROFILE = []
+        for _ in range(3):
+            tstep()
+        torch.cuda.synchronize()
+        tprof, _ops.PROFILE = _ops.PROFILE, None
+        tper = {}
+        for tag, e0, e1 in tprof:
+            tper.setdefault(tag, []).append(e0.elapsed_time(e1))
+        tk = []
+        for tag, ts in tper.items():
+            d = dict(zip(tag[::2], tag[1::2]))
+            ms = sum(ts) / len(ts)
+            if "nnz" in d:
+                b = pass_bytes(d["nnz"], d["rows"], d["cols"], d["D"], G)
+                tk.append({"kernel": d["kernel"], "rows": d["rows"], "src_rows": d["cols"], "D": d["D"], "launches_per_step": len(ts) // 3,
+                           "avg_ms": round(ms, 4), "bound": "hbm", "alg_bytes": b, "achieved_GBs": round(b / ms / 1e6, 1),
+                           "frac": round(b / ms / 1e6 / HBM_PEAK_GBS, 4)})
+            else:
+                fl = 2.0 * d["rows"] * d["N"] * d["K"]
+                tk.append({"kernel": d["kernel"], "M": d["rows"], "N": d["N"], "K": d["K"], "launches_per_step": len(ts) // 3,
+                           "avg_ms": round(ms, 4), "bound": "mfma", "flops": fl, "achieved_TFLOPs": round(fl / ms / 1e9, 1),
+                           "peak_TFLOPs": 157.3, "frac": round(fl / ms / 1e9 / 157.3, 4)})
+        tk.sort(key=lambda k: -k["avg_ms"] * k["launches_per_step"])
+        train_step = {"ms_per_step": round(t_train, 4), "steps": n_tr, "loss": round(float(tl), 2),
                       "what": f"full-batch {cfg.name} training step at N = 1: forward (dropout 0.1) + CrossEntropyLoss(sum) + backward "
-                              "(K2t on pre-scaled rows, wgnn_agg_bwd_prepare, matrix-core weight gradients) + fused Adam"}
+                              "(K2t on pre-scaled rows, wgnn_agg_bwd_prepare, matrix-core weight gradients) + fused Adam",
+                      "kernels": tk,
+                      "kernels_ms_per_step": round(sum(k["avg_ms"] * k["launches_per_step"] for k in tk), 4)}
         del tm, topt, tf
 
     # ---- secondary (never `value`): the one-shot path - graph build, plan build, first forward, predictor-shaped end to end

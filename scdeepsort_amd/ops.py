@@ -76,6 +76,26 @@ def will_run_tiled(csr: AggCsr, D: int, n_seed_rows: Optional[int] = None) -> bo
     return tiled_kernel_serves(csr, D) and (n_seed_rows is None or n_seed_rows >= SEED_FULL_PASS_MIN_FRAC * csr.n_rows)
 
 
+class _Timed:
+    """``with _Timed(dev, tag):`` records one (tag, start, end) HIP-event triple into ``PROFILE`` on the launch stream
+    (a no-op when no profile is being collected)."""
+
+    def __init__(self, dev, tag):
+        self.dev, self.tag, self.ev = dev, tag, None
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self.ev[0].record(torch.cuda.current_stream(self.dev))
+        return self
+
+    def __exit__(self, *exc):
+        if self.ev is not None and PROFILE is not None:
+            self.ev[1].record(torch.cuda.current_stream(self.dev))
+            PROFILE.append((self.tag, self.ev[0], self.ev[1]))
+        return False
+
+
 def _partials(plan: Plan, D: int, device) -> Optional[torch.Tensor]:
     return torch.empty(plan.n_partials * D, dtype=torch.float32, device=device) if plan.n_partials else None
 
@@ -197,12 +217,14 @@ def agg_bwd_src(csr: AggCsr, alpha: Optional[torch.Tensor], mode: int, g: torch.
             scratch = torch.empty_like(g)
         part = torch.empty(tp.n_partials * D, dtype=torch.float32, device=dev) if tp.n_partials else None
         n_long = tp.long_rows.shape[0]
-        rc = _lib.call(dev, "wgnn_agg_bwd_src_tiled",
-            _ptr(alpha), mode, _ptr(scale), _ptr(g), g.shape[0], _ptr(scratch),
-            _ptr(h_src), h_src.stride(0) if h_src is not None else 0, _ptr(dh_src), dh_src.stride(0), _ptr(dalpha),
-            int(accumulate), t.n_rows, D, _ptr(tp.entries), _ptr(tp.seg_ptr), tp.nblk_max, tp.block_rows_arg,
-            _ptr(tp.items), _ptr(tp.hdr), tp.n_tiles, _ptr(tp.long_rows) if n_long else None, n_long,
-            _ptr(part), tp.n_partials, _stream(dev))
+        with _Timed(dev, ("rows", t.n_rows, "cols", t.n_cols, "nnz", t.nnz, "D", D, "mode", mode, "kernel",
+                          "agg_tiled_tall<EPI_BWD_SRC>" if tp.geom.tall else "agg_tiled_flat4<EPI_BWD_SRC>")):
+            rc = _lib.call(dev, "wgnn_agg_bwd_src_tiled",
+                _ptr(alpha), mode, _ptr(scale), _ptr(g), g.shape[0], _ptr(scratch),
+                _ptr(h_src), h_src.stride(0) if h_src is not None else 0, _ptr(dh_src), dh_src.stride(0), _ptr(dalpha),
+                int(accumulate), t.n_rows, D, _ptr(tp.entries), _ptr(tp.seg_ptr), tp.nblk_max, tp.block_rows_arg,
+                _ptr(tp.items), _ptr(tp.hdr), tp.n_tiles, _ptr(tp.long_rows) if n_long else None, n_long,
+                _ptr(part), tp.n_partials, _stream(dev))
         _lib.check(rc, "wgnn_agg_bwd_src_tiled")
         return dh_src
     if prescaled:
@@ -680,8 +702,9 @@ def linear_wgrad(g: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     _lib.check(_lib.lib().wgnn_linear_wgrad_workspace(M, N, K, C.addressof(ns), C.addressof(nb)), "wgnn_linear_wgrad_workspace")
     ws = torch.empty(max(1, nb.value // 4), dtype=torch.float32, device=dev)
     dW = torch.empty((N, K), dtype=torch.float32, device=dev)
-    rc = _lib.call(dev, "wgnn_linear_wgrad", _ptr(g), g.stride(0), _ptr(x), x.stride(0), _ptr(dW), K, M, N, K, 0, _ptr(ws),
-                   ns.value, _stream(dev))
+    with _Timed(dev, ("rows", M, "N", N, "K", K, "kernel", "wgrad_mfma_f32 + wgrad_reduce")):
+        rc = _lib.call(dev, "wgnn_linear_wgrad", _ptr(g), g.stride(0), _ptr(x), x.stride(0), _ptr(dW), K, M, N, K, 0, _ptr(ws),
+                       ns.value, _stream(dev))
     _lib.check(rc, "wgnn_linear_wgrad")
     return dW
 
