@@ -52,7 +52,8 @@ extern "C" {
                                       0.2.2: WGNN_FLAG_OUT_SCALE_ALPHA (an older library ignores the bit: callers that set it
                                       need >= 202).  0.2.3: wgnn_agg_bwd_prepare, wgnn_ce_sum_fwd_bwd; wgnn_agg_bwd_src_tiled
                                       takes col_scale == NULL (pre-scaled gradient rows).  0.2.4: WGNN_PLAN_TALL (tall tile
-                                      plans: 8 waves x 49 rows). */
+                                      plans: 8 waves x 49 rows),
+                                      wgnn_tile_plan_count / wgnn_tile_plan_fill. */
 
 /* Tile-plan geometry, OR-ed into the `block_rows` argument of wgnn_agg_fwd_tiled / wgnn_agg_bwd_src_tiled /
  * wgnn_agg_bwd_alpha_tiled (0.2.4; an older library rejects the bit with WGNN_ERR_PLAN): the plan was built for the TALL tile -
@@ -176,10 +177,10 @@ int wgnn_agg_fwd(const void* rowptr /* int32_t[R+1]; int64_t[R+1] with WGNN_FLAG
  *                                          global->LDS stream while the other waves only compute (a plan that gives every
  *                                          wave rows keeps all 16 waves streaming their share; same results either way)
  *   entries    : int32[n_entries * 2]      {meta, weight (f32 bits)}, grouped by (tile, block, wave) segment;
- *                                          block = (col - col_begin) / block_rows.  meta = dst_slot_in_wave << 8 |
- *                                          src_row_in_block (bits 0..11), any order inside a segment, plus optionally
+ *                                          block = (col - col_begin) / block_rows.  meta = dst_slot_in_wave << 8 (bits 8..13) |
+ *                                          src_row_in_block (bits 0..7), any order inside a segment, plus optionally
  *                                          SHARED PAIRS: two entries of a segment on the same source row may be marked
- *                                          (bit 31 on both, the first also carrying the second's slot in bits 16..19);
+ *                                          (bit 31 on both, the first also carrying the second's slot in bits 16..21);
  *                                          the kernel then stages that source row once for both.  Marked pairs must be the
  *                                          LAST entries of their segment and start at an even offset from the segment's
  *                                          begin (pad the unmarked run with a zero-weight copy of its last entry; bit 30
@@ -374,6 +375,30 @@ int wgnn_ce_sum_workspace(int64_t n_rows, int64_t* floats);
 int wgnn_ce_sum_fwd_bwd(const float* logits, int64_t ld_logits, const int64_t* labels, int64_t n_rows, int32_t n_classes,
                         float* loss_sum, float* dlogits, int64_t ld_dlogits, float* workspace, int64_t workspace_floats,
                         void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Tile-plan construction on the device (0.2.4).  `entries` / `seg_ptr` of a tile plan (see wgnn_agg_fwd_tiled) from the CSR
+ * and the row -> (tile, wave, slot) assignment, without a sort: one wavefront per (tile, wave) walks its <= 64 destination rows
+ * (their non-zeros are sorted by column) in lock step through the tile's source range.  Two passes over the same arguments:
+ *   wgnn_tile_plan_count : seg_total[s] = entries of segment s, seg_pairs[s] = those that pair up on a source row
+ *                          (s = (tile * nblk_max + block) * waves + wave; arrays zero-initialised by the caller)
+ *   caller               : seg_ptr = exclusive prefix sum of seg_total + pad, pad = (seg_total - seg_pairs) odd && seg_pairs > 0
+ *   wgnn_tile_plan_fill  : entries[seg_ptr[s] ..) = [unshared][pad][shared pairs] of every segment
+ *   slot_vrow : int32[n_row_tiles * waves * rpw]   virtual row of (row tile, wave, slot) | -1
+ *   vrow_*    : per virtual row: CSR row, part j, parts k  (the row's non-zeros j, j + k, j + 2k, ...; k = 1: the whole row)
+ *   flat_t    : int32[n_tiles]  row tile of the tile launched at position f;  tile_hdr as in wgnn_agg_fwd_tiled
+ *   waves x rpw : 16 x 16 or 8 x 49 (WGNN_PLAN_TALL); block_rows: source rows per LDS block (<= 255)
+ * Deterministic, no atomics, no allocation; col / rowptr are int32 (an operand holds < 2^31 non-zeros per GPU).
+ * ------------------------------------------------------------------------- */
+int wgnn_tile_plan_count(const int32_t* rowptr, const int32_t* col, const int32_t* slot_vrow,
+                         const int32_t* vrow_row, const int32_t* vrow_part, const int32_t* vrow_k,
+                         const int32_t* flat_t, const int32_t* tile_hdr, int64_t n_tiles, int32_t waves, int32_t rpw,
+                         int32_t nblk_max, int32_t block_rows, int32_t* seg_total, int32_t* seg_pairs, void* stream);
+int wgnn_tile_plan_fill(const int32_t* rowptr, const int32_t* col, const float* val, const int32_t* slot_vrow,
+                        const int32_t* vrow_row, const int32_t* vrow_part, const int32_t* vrow_k,
+                        const int32_t* flat_t, const int32_t* tile_hdr, int64_t n_tiles, int32_t waves, int32_t rpw,
+                        int32_t nblk_max, int32_t block_rows, const int32_t* seg_total, const int32_t* seg_pairs,
+                        const int32_t* seg_ptr, int32_t* entries, void* stream);
 
 #ifdef __cplusplus
 }

@@ -54,6 +54,8 @@ SIGNATURES = {
                                        _i64, _i32, _vp, _i64, _vp]),
     "wgnn_ce_sum_workspace": (C.c_int, [_i64, _vp]),
     "wgnn_ce_sum_fwd_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _i64, _vp]),
+    "wgnn_tile_plan_count": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "wgnn_tile_plan_fill": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "wgnn_agg_linear_relu_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _int, _i32, _vp, _i64, _vp, _i64, _vp, _vp,
                                            _i64, _i32, _u32, _vp, _i64, _vp, _i64, _vp, _i64, _vp,
                                            _vp, _i64, _vp, _i32, _u32, _vp, _i64, _vp]),

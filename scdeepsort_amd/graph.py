@@ -653,6 +653,9 @@ def auto_tile_geometry(n_rows: int, n_cols: int, n_cus: int = 256, nnz: Optional
 
 
 TILE_ORDER = "xcd"       # "xcd" | "split_major" (round-1 order; kept for A/B timing)
+# Round 5: the entries of a plan are built by the library's plan walk (csrc/wgnn_plan.hip: one wavefront per (tile, wave), no
+# sort) when the operand lives on a GPU; False (or a CPU operand - the unit tests) = the framework index arithmetic below.
+TILE_PLAN_KERNEL = __import__("os").environ.get("WGNN_TILE_PLAN_KERNEL", "1") == "1"
 
 
 def _flat_tile_index(n_col_splits: int, n_row_tiles: int, dev) -> torch.Tensor:
@@ -794,10 +797,39 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
     long_rows = torch.stack([lr, pbase[lr], n_parts_r[lr], torch.zeros_like(lr)], 1).to(torch.int32).contiguous() \
         if lr.numel() else torch.empty((0, 4), dtype=torch.int32, device=dev)
     # ---- entries: the CSR re-ordered by (tile, block, wave, destination slot)
+    nblk_max = max(1, per_split // blk)
+    n_seg = n_col_splits * n_row_tiles * nblk_max * TILE_WAVES
+    if (TILE_PLAN_KERNEL and TILE_SHARED_PAIRS and dev.type == "cuda" and total < 2 ** 31 - 1 and csr.rowptr.dtype == torch.int32
+            and csr.col.dtype == torch.int32 and csr.val.dtype == torch.float32 and n_seg < 2 ** 31 - 1):
+        # the library's plan walk: count, prefix sum, fill (csrc/wgnn_plan.hip)
+        slot_vrow = torch.full((n_row_tiles * TILE_ROWS,), -1, dtype=torch.int32, device=dev)
+        slot_vrow[tile * TILE_ROWS + local] = order.to(torch.int32)
+        vrow32, vpart32, vk32 = vrow.to(torch.int32), vpart.to(torch.int32), k_r[vrow].to(torch.int32)
+        flat_t = torch.empty(n_flat, dtype=torch.int32, device=dev)
+        flat_t[flat_of.reshape(-1)] = torch.arange(n_row_tiles, device=dev, dtype=torch.int32).repeat(n_col_splits)
+        hdr_c = hdr.contiguous()
+        seg_total = torch.zeros(n_seg, dtype=torch.int32, device=dev)
+        seg_pairs = torch.zeros(n_seg, dtype=torch.int32, device=dev)
+        rowptr_c, col_c, val_c = csr.rowptr.contiguous(), csr.col.contiguous(), csr.val.contiguous()
+        common = (_ptr(slot_vrow), _ptr(vrow32), _ptr(vpart32), _ptr(vk32), _ptr(flat_t), _ptr(hdr_c), n_flat, TILE_WAVES,
+                  TILE_ROWS // TILE_WAVES, nblk_max, blk)
+        _lib.check(_lib.call(dev, "wgnn_tile_plan_count", _ptr(rowptr_c), _ptr(col_c), *common, _ptr(seg_total), _ptr(seg_pairs),
+                             _stream(dev)), "wgnn_tile_plan_count")
+        pad = ((seg_total - seg_pairs) & 1) * (seg_pairs > 0)
+        seg_ptr = torch.zeros(n_seg + 1, dtype=torch.int64, device=dev)
+        torch.cumsum(seg_total + pad, 0, out=seg_ptr[1:])
+        n_entries = int(seg_ptr[-1])
+        if n_entries >= 2 ** 31 - 1:
+            raise ValueError("tile plan with >= 2^31 entries: shard the operand")
+        seg_ptr32 = seg_ptr.to(torch.int32)
+        entries = torch.empty((n_entries, 2), dtype=torch.int32, device=dev)
+        _lib.check(_lib.call(dev, "wgnn_tile_plan_fill", _ptr(rowptr_c), _ptr(col_c), _ptr(val_c), *common, _ptr(seg_total),
+                             _ptr(seg_pairs), _ptr(seg_ptr32), _ptr(entries), _stream(dev)), "wgnn_tile_plan_fill")
+        return TilePlan(items.contiguous(), hdr_c, long_rows, n_part,
+                        n_row_tiles, n_col_splits, n_loaders, entries, seg_ptr32, nblk_max, block_rows, geom)
     tile_v = torch.empty(V, dtype=torch.int64, device=dev); tile_v[order] = tile
     wave_v = torch.empty(V, dtype=torch.int64, device=dev); wave_v[order] = wave
     slot_v = torch.empty(V, dtype=torch.int64, device=dev); slot_v[order] = slot_in_wave
-    nblk_max = max(1, per_split // blk)
     # (round 5: 32-bit index arithmetic and one gather per non-zero where the operand allows it - these are 8e7-element passes)
     i32 = total < 2 ** 31 - 1 and n_col_splits * n_row_tiles * nblk_max * TILE_WAVES < 2 ** 31 - 1
     it = torch.int32 if i32 else torch.int64
@@ -825,7 +857,6 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
         del ksplit, rel
     meta = ((slot_v.to(torch.int32)[virt] << 8) | src_local.to(torch.int32))
     del colv, src_local
-    n_seg = n_col_splits * n_row_tiles * nblk_max * TILE_WAVES
     val_bits = csr.val.view(torch.int32)
     if not TILE_SHARED_PAIRS:
         key = key.long() * (TILE_ROWS // TILE_WAVES) + slot_v[virt]

@@ -1743,6 +1743,71 @@ def test_tile_kernel_dedicated_loader_waves(kb, D, direction):
     np.testing.assert_allclose(run(crowded).cpu().numpy(), want, atol=TOL)
 
 
+def test_plan_walk_kernel_builds_the_same_plans_as_the_framework_builder():
+    """Round 5: `wgnn_tile_plan_count` / `wgnn_tile_plan_fill` (csrc/wgnn_plan.hip: one wavefront per (tile, wave) walks its rows
+    in lock step, no sort) against the framework-arithmetic builder of rounds 1-4 on the same operands: identical segment
+    boundaries, the same (row, column, weight) multiset per segment, the [unshared][pad][pairs] layout with its invariants,
+    and the same forward through either plan - for both tile geometries, column splits, virtual rows of a hub gene, loader
+    waves, a support-masked gene side and empty rows."""
+    from scdeepsort_amd import ops, graph as GR
+    c = small_case(cells=2300, genes=520, dim=64, seed=91, density=0.12, test_cells=60)
+    g = sda.CellGeneGraph.from_expression(c["expr"], c["support_mask"], device=DEV)
+    G = c["G"]; rng = np.random.default_rng(4)
+    alpha = dev(rng.uniform(0.5, 1.5, G + 2).astype(np.float32))
+    Hg, Hc = dev(c["feats"][:G]), dev(c["feats"][G:])
+    cases = [(g.cg, sda.SRC_IS_GENE, G + 1, Hg, Hc), (g.gc, sda.DST_IS_GENE, G, Hc, Hg)]
+    for csr, mode, sidx, src, slf in cases:
+        for geom, rt, cs, kb, L in ((GR.GEOM_FLAT, None, None, 64, 1), (GR.GEOM_FLAT, -(-csr.n_rows // 256), 3, 23, 0),
+                                    (GR.GEOM_FLAT, 12, 1, 78, 2), (GR.GEOM_TALL, None, None, 64, 0), (GR.GEOM_TALL, 7, 2, 40, 0)):
+            plans = {}
+            for kern in (True, False):
+                saved, GR.TILE_PLAN_KERNEL = GR.TILE_PLAN_KERNEL, kern
+                try:
+                    plans[kern] = GR.build_tile_plan(csr, rt, cs, block_rows=kb, n_loaders=L, geom=geom)
+                finally:
+                    GR.TILE_PLAN_KERNEL = saved
+            a, b = plans[True], plans[False]
+            assert torch.equal(a.items, b.items) and torch.equal(a.hdr, b.hdr) and a.n_loaders == b.n_loaders
+            assert torch.equal(a.seg_ptr, b.seg_ptr), (geom, rt, cs, kb)
+            assert a.entries.shape == b.entries.shape
+            W, rpw = geom.waves, geom.rpw
+            seg = a.seg_ptr.long(); n_seg = seg.shape[0] - 1
+            per = seg[1:] - seg[:-1]
+            sid = torch.repeat_interleave(torch.arange(n_seg, device=DEV), per)
+            off = torch.arange(a.entries.shape[0], device=DEV) - seg[sid]
+
+            def decode(tp):
+                meta, wb = tp.entries[:, 0].long(), tp.entries[:, 1]
+                slot, srcl = (meta >> 8) & 0x3F, meta & 0xFF
+                paired, padded = meta < 0, (meta & GR.TILE_PAD_FLAG) != 0
+                wave, blk, tile = sid % W, (sid // W) % tp.nblk_max, sid // (W * tp.nblk_max)
+                slots = tp.items[:, :, 0].reshape(tp.n_tiles, W, rpw)
+                row = slots[tile, wave, slot].long()
+                col = tp.hdr[tile, 0].long() + blk * tp.block_rows + srcl
+                key = (sid * (csr.n_rows + 1) + row) * (csr.n_cols + 1) + col          # (segment, row, column)
+                keep = ~padded
+                order = torch.argsort(key[keep])
+                return key[keep][order], wb[keep][order], meta, paired, padded, slot, srcl
+            ka, wa, meta, paired, padded, slot, srcl = decode(a)
+            kb_, wb_, *_ = decode(b)
+            assert torch.equal(ka, kb_) and torch.equal(wa, wb_)                        # same entries in every segment
+            # layout invariants of the kernel-built plan
+            assert (a.entries[:, 1][padded] == 0).all() and not (paired & padded).any()
+            first = torch.nonzero(paired & (off % 2 == 0)).squeeze(1)
+            assert first.numel() * 2 == int(paired.sum())
+            assert paired[first + 1].all() and (sid[first + 1] == sid[first]).all() and (srcl[first + 1] == srcl[first]).all()
+            assert (((meta[first] >> 16) & 0x3F) == slot[first + 1]).all()
+            n_pair = torch.bincount(sid[paired], minlength=n_seg)
+            assert (paired == (off >= (per - n_pair)[sid])).all() and ((per - n_pair)[n_pair > 0] % 2 == 0).all()
+            assert (torch.bincount(sid[padded], minlength=n_seg)[n_pair == 0] == 0).all()
+            pp = torch.nonzero(padded).squeeze(1)
+            assert ((meta[pp] & 0xFFFF) == (meta[pp - 1] & 0xFFFF)).all()               # a zero-weight copy of the entry before it
+            out_a = ops.agg_fwd_tiled(csr, a, alpha, mode, sidx, src, slf)
+            out_b = ops.agg_fwd_tiled(csr, b, alpha, mode, sidx, src, slf)
+            np.testing.assert_allclose(out_a.cpu().numpy(), out_b.cpu().numpy(), atol=2e-5, rtol=1e-5)
+    assert GR.TILE_PLAN_KERNEL                                                          # the kernel is the default on the GPU
+
+
 @pytest.mark.parametrize("D", [64, 200, 256])
 def test_tall_tile_kernel_matches_the_oracle_and_the_flat_kernel(D):
     """Round 5: agg_tiled_tall - the entry pipeline on 8 waves x 256 VGPRs, 49 destination rows per wave (`graph.GEOM_TALL`,
