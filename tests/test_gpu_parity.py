@@ -2340,7 +2340,7 @@ def test_full_size_cfg5_sharded_eight_ways_matches_unsharded():
             assert got.shape == (hi - lo, cfg.n_classes)
             worst = max(worst, (got - want[lo:hi]).abs().max().item())
             tp = [k for k in eng.graph.cg._tile_plan]        # both geometries of the cells side were used: overlapped pass, last layer
-            assert {k[-1] for k in tp} == {224, 256}
+            assert {k[3] for k in tp} == {224, 256}             # key = (block rows, loaders, pairs, CU budget, geometry)
             del eng
     assert worst < 1e-4, worst
 
