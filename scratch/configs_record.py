@@ -1,4 +1,4 @@
-"""Round 4 records -> gpurun_out/r04_configs.json (copied to profiles/):
+"""Records of the other BASELINE configs -> gpurun_out/r05_configs.json (copied to profiles/):
   cfg2 forward (hipGraph replay), cfg5 (764,741 cells, fp16-stored features) forward on ONE GPU, cfg4's full-batch training
   step at N = 1, and DeepSortPredictor-shaped inference at atlas scale: a predict graph of 10k support cells + 100k test
   cells over 20k genes, every test cell a seed (predict.py:61-88), the reference's predict-time sizes dense_dim 400 /
@@ -8,7 +8,7 @@ from pathlib import Path
 import torch, torch.nn.functional as F
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-out = {"_how": "python scratch/configs_record_r04.py on one MI355X (gpurun); bench entries are the command's own output line"}
+out = {"_how": "python scratch/configs_record.py on one MI355X (gpurun); bench entries are the command's own output line"}
 def run(cmd, env=None, timeout=900):
     t = time.time()
     r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, **(env or {})))
@@ -72,6 +72,6 @@ for L in (1, 2):
 out["predictor_shaped_inference"] = {"graph": f"{n_sup} support + {n_test} test cells x {G} genes, nnz {g.cg.nnz}, dense_dim 400, hidden 200",
                                       "call": "GNN.forward(graph, feats, seeds = every test cell)  [DeepSortPredictor.predict, predict.py:61-88]", **pred}
 Path(ROOT / "gpurun_out").mkdir(exist_ok=True)
-(ROOT / "gpurun_out" / "r04_configs.json").write_text(json.dumps(out, indent=1))
+(ROOT / "gpurun_out" / "r05_configs.json").write_text(json.dumps(out, indent=1))
 print(json.dumps(out["predictor_shaped_inference"], indent=1))
 print({k: (v.get("line", {}).get("ms_per_step"), v.get("stdout")) for k, v in out.items() if isinstance(v, dict) and k != "predictor_shaped_inference"})
