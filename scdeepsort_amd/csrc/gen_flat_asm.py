@@ -94,6 +94,8 @@ HALF = "halfmodel" in ABLATE     # timing only (D <= 128): the cost structure of
                                  # ds_read_b128 (lanes 0-31 one source row, lanes 32-63 the other) and one pair of packed FMAs
 IDXMODE = "idxmode" in ABLATE    # a REAL variant (results stay correct): GPR-index mode is switched on ONCE per chunk; a step only moves
                                  # the index (s_set_gpr_idx_idx) and parks it at 0 behind its FMAs - no MODE-register write per step
+WRLS = "wrls" in ABLATE          # a REAL variant: the SHARED-pair stream takes its weights through v_readlane (SGPR operands of the FMAs)
+                                 # instead of the broadcast ds_read_b64 - trades 2 LDS clk per pair for 2 VALU (the LDS is the busier pipe)
 SMEM = "smem" in ABLATE          # timing only, with norl,nowt: the cost side of a scalar-cache entry feed - every 4th pair step drains
                                  # lgkmcnt (SMEM returns out of order: only 0 proves a scalar load landed) and issues one
                                  # s_load_dwordx16 (8 entries = 4 pairs) from the chunk's own address (operand %[ep], clobbers s[64:79])
@@ -183,6 +185,16 @@ def fmas(p):
             "s_set_gpr_idx_idx 0" if IDXMODE else "s_set_gpr_idx_off"]
 
 
+def s_wsgpr(p):
+    """WRLS: SGPR pairs of a shared pair's two weights (low words; the odd halves are free - s87 serves as SSLOT)."""
+    return (86, 88) if p % 2 == 0 else (90, 92)
+
+
+def s_wreadlanes(p):
+    wa, wb = s_wsgpr(p)
+    return [f"v_readlane_b32 s{wa}, %[wv], {2 * p}", f"v_readlane_b32 s{wb}, %[wv], {2 * p + 1}"]
+
+
 def s_readlanes(p):
     if NORL:
         return []
@@ -196,7 +208,7 @@ def s_addresses(p):
 def s_reads(p):
     x0, _ = xreg(p)
     w = wreg(p)
-    return [f"ds_read_b128 v[{x0}:{x0 + 3}], v{M['a0']}"] + ([] if NOWT else [f"ds_read_b64 v[{w}:{w + 1}], %[wb] offset:{8 * p}"])
+    return [f"ds_read_b128 v[{x0}:{x0 + 3}], v{M['a0']}"] + ([] if (NOWT or WRLS) else [f"ds_read_b64 v[{w}:{w + 1}], %[wb] offset:{8 * p}"])
 
 
 def s_fmas(p):
@@ -205,6 +217,16 @@ def s_fmas(p):
     x0, _ = xreg(p)
     w = f"v[{wreg(p)}:{wreg(p) + 1}]"
     lo, hi = "op_sel_hi:[0,1,1]", "op_sel:[1,0,0] op_sel_hi:[1,1,1]"
+    if WRLS:
+        wa, wb = s_wsgpr(p)
+        return [f"s_set_gpr_idx_on s{s['pk0']}, gpr_idx(SRC2,DST)",
+                f"v_pk_fma_f32 {acc(0)}, s[{wa}:{wa + 1}], v[{x0}:{x0 + 1}], {acc(0)} {lo}",
+                f"v_pk_fma_f32 {acc(2)}, s[{wa}:{wa + 1}], v[{x0 + 2}:{x0 + 3}], {acc(2)} {lo}",
+                f"s_lshr_b32 s87, s{s['pk0']}, 18",
+                "s_set_gpr_idx_idx s87",
+                f"v_pk_fma_f32 {acc(0)}, s[{wb}:{wb + 1}], v[{x0}:{x0 + 1}], {acc(0)} {lo}",
+                f"v_pk_fma_f32 {acc(2)}, s[{wb}:{wb + 1}], v[{x0 + 2}:{x0 + 3}], {acc(2)} {lo}",
+                "s_set_gpr_idx_off"]
     return [f"s_set_gpr_idx_idx s{s['pk0']}" if IDXMODE else f"s_set_gpr_idx_on s{s['pk0']}, gpr_idx(SRC2,DST)",
             f"v_pk_fma_f32 {acc(0)}, {w}, v[{x0}:{x0 + 1}], {acc(0)} {lo}",
             f"v_pk_fma_f32 {acc(2)}, {w}, v[{x0 + 2}:{x0 + 3}], {acc(2)} {lo}",
@@ -222,8 +244,10 @@ def s_step(p):
     out = [f".Lw4_sstep{p}_%=:"]
     R = s_reads(p + 1) if p + 1 < N_PAIRS else []
     L = s_readlanes(p + 2) if p + 2 < N_PAIRS else []
+    if WRLS and p + 1 < N_PAIRS:
+        L = L + s_wreadlanes(p + 1)
     A = s_addresses(p + 2) if p + 2 < N_PAIRS else []
-    W = [f"s_waitcnt lgkmcnt({(1 if NOWT else 2) * min(1, N_PAIRS - 1 - p)})"]
+    W = [f"s_waitcnt lgkmcnt({(1 if (NOWT or WRLS) else 2) * min(1, N_PAIRS - 1 - p)})"]
     return out + R + L + A + W + s_fmas(p) + smem_refill(p)
 
 
@@ -253,7 +277,7 @@ def step(p):
     if "xlds" in ABLATE:
         out += ["ds_read_b32 v39, %[wb]"]
     if SHARED and p + 1 < N_PAIRS:                    # pairs p+1 .. 31 are shared pairs: continue in that stream
-        out += [f"s_cmp_eq_u32 %[sw], {p + 1}", f"s_cbranch_scc1 .Lw4_sstep{p + 1}_%="]
+        out += [f"s_cmp_eq_u32 %[sw], {p + 1}", f"s_cbranch_scc1 .Lw4_{'sentry' if WRLS else 'sstep'}{p + 1}_%="]
     return out
 
 
@@ -302,6 +326,10 @@ def pipeline_lines():
         lines.append("s_branch .Lw4_end_%=")
         for p in range(1, N_PAIRS):
             lines += s_step(p)
+        if WRLS:                                          # hand-over stubs: the first shared pair's weights, then its step
+            lines.append("s_branch .Lw4_end_%=")
+            for p in range(1, N_PAIRS):
+                lines += [f".Lw4_sentry{p}_%=:"] + s_wreadlanes(p) + [f"s_branch .Lw4_sstep{p}_%="]
         lines.append(".Lw4_end_%=:")
     if IDXMODE:
         if not SHARED:
