@@ -108,12 +108,58 @@ def cpu_baseline(graph, model, feats_g, feats_c, gpu_logits, cfg):
             "all": every}
 
 
+def describe_workload(col, cells, genes, popularity, S):
+    """What was generated, measured on the operand itself: inclusion frequency (share of this rank's cells expressing the gene) at
+    SURVEY 8d's five popularity ranks - taken at the same QUANTILE of the gene list (rank * G / 9339) and at the absolute rank."""
+    pop = torch.sort(torch.bincount(col.long(), minlength=genes).double() / max(cells, 1), descending=True).values
+
+    def at(r):
+        lo, hi = max(0, int(r / 1.1) - 1), min(genes, int(r * 1.1) + 1)
+        return round(float(pop[lo:hi].mean()), 4)
+    ranks = (1, 10, 100, 1000, 3000)
+    return {"popularity": popularity,
+            "rng": "numpy.random.default_rng(seed), seed 10086 (+ rank in weak mode)" if popularity == "testis199" else "torch device generator",
+            "survey_8d_inclusion_at_rank_1_10_100_1000_3000_of_9339": [0.98, 0.67, 0.32, 0.09, 0.035],
+            "inclusion_at_same_quantile": [at(max(1, r * genes / S.TESTIS_GENES)) for r in ranks],
+            "inclusion_at_absolute_rank": [at(r) for r in ranks],
+            "median_gene_inclusion": round(float(pop[genes // 2]), 4),
+            "top256_genes_edge_share": round(float(pop[:256].sum() / pop.sum()), 4)}
+
+
+def shared_pair_share(plan):
+    """Share of a tile plan's entries that ride the shared-pair stream (two entries per LDS row read)."""
+    if plan is None or plan.entries is None:
+        return None
+    meta = plan.entries[:, 0]
+    real = int(((meta & (1 << 30)) == 0).sum())
+    return round(int((meta < 0).sum()) / max(real, 1), 4)
+
+
+def popularity_note():
+    """The non-default popularity law is part of the workload's name; SURVEY 8d's law (the default) is not spelled out."""
+    p = os.environ.get("WGNN_SYNTH_POPULARITY", "testis199")
+    return "" if p == "testis199" else f" ({p} popularity - NOT SURVEY 8d's generator)"
+
+
+KERNEL_SOURCES = ("wgnn_tiled.hip", "gen_flat_asm.py", "wgnn_flat_asm.inc", "wgnn_common.h", "wgnn_kernels.hip")
+
+
+def kernel_sources_sha():
+    """Content hash of the sources of the aggregation kernels: profiles/hbm_traffic.json is stamped with it at capture time
+    (scratch/profile_round.sh) and `roofline.traffic` is null when the tree's kernels are no longer the captured ones."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        h.update((ROOT / "scdeepsort_amd" / "csrc" / name).read_bytes())
+    return h.hexdigest()
+
+
 def workload_string(cfg, total_cells, mode):
     """`config.workload` of the line.  A pure function of the config and the scaling mode - NOT of the number of ranks - so that
     the N = 1 leg of a SCALE run names the same workload as the BENCH line (tests/test_host_logic.py pins it)."""
     return (f"{cfg.name}: {total_cells} cells x {cfg.genes} genes"
             f"{' (ONE job, cells sharded over the ranks)' if mode == 'strong' else ' in total (' + str(cfg.cells) + ' per GPU)'}, "
-            f"density {cfg.density}, dense_dim {cfg.dense_dim}, hidden {cfg.hidden}, "
+            f"density {cfg.density}{popularity_note()}, dense_dim {cfg.dense_dim}, hidden {cfg.hidden}, "
             f"{cfg.n_layers}-layer WGNN forward + {cfg.n_classes}-class head")
 
 
@@ -291,10 +337,14 @@ def main():
                          "at N > 1 only with `on`: the captured sharded forward is then timed against eager issue and the faster one runs)")
     ap.add_argument("--hidden", type=int, default=None, help="override the config's hidden width (e.g. 200, the reference's default "
                                                              "hidden_dim, train.py:137) - a side measurement, not BASELINE's line")
+    ap.add_argument("--popularity", choices=("testis199", "dense_head"), default=os.environ.get("WGNN_SYNTH_POPULARITY", "testis199"),
+                    help="gene popularity law of the synthetic graph: testis199 = SURVEY 8d's (the demo file's inclusion curve, numpy "
+                         "default_rng), dense_head = rounds 1-5's generator (rank^-0.9 taken literally, denser head) for A/B")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the weak-scaling / sustained secondary measurements")
     args = ap.parse_args()
 
+    os.environ["WGNN_SYNTH_POPULARITY"] = args.popularity       # every synth_expression of this run (and of its child ranks)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args)                                        # does not return
     rank = int(os.environ.get("RANK", 0)); local_rank = int(os.environ.get("LOCAL_RANK", 0))
@@ -346,6 +396,7 @@ def main():
     torch.cuda.synchronize()
     t_generate = time.time() - t_setup
     C = feats_c.shape[0]                             # cells held by THIS rank
+    generator_desc = describe_workload(col, C, G, args.popularity, S)
     torch.manual_seed(1234)
     model = sda.GNN(cfg.dense_dim, cfg.hidden, cfg.n_classes, cfg.n_layers, G, activation=F.relu)
     with torch.no_grad():
@@ -468,10 +519,18 @@ def main():
         try:
             rec = json.loads(tf.read_text())
             ent = rec.get(f"{args.config}:{dom['rows']}x{dom['src_rows']}")
-            if isinstance(ent, dict) and ent.get("kernel") == dom["kernel"] and int(ent.get("D", 256)) == dom["D"]:
-                traffic = ent["hbm_bytes_per_launch"]
-                traffic_src = ("TRACKED capture, not a counter of this run (PMC needs rocprofv3 around the whole process): "
-                               f"profiles/hbm_traffic.json ({rec.get('_captured', '?')})")
+            fresh = rec.get("_kernel_sources_sha") == kernel_sources_sha() and rec.get("_popularity") == args.popularity
+            if (isinstance(ent, dict) and ent.get("kernel") == dom["kernel"] and int(ent.get("D", 256)) == dom["D"]
+                    and ent.get("nnz", dom["nnz"]) == dom["nnz"]):
+                if fresh:
+                    traffic = ent["hbm_bytes_per_launch"]
+                    traffic_src = ("TRACKED capture, not a counter of this run (PMC needs rocprofv3 around the whole process): "
+                                   f"profiles/hbm_traffic.json ({rec.get('_captured', '?')}; commit {rec.get('_commit', '?')}, "
+                                   f"kernel sources {rec.get('_kernel_sources_sha', '?')[:12]} == this tree's)")
+                else:
+                    traffic_src = ("null: profiles/hbm_traffic.json was captured from other kernel sources or another workload "
+                                   f"(capture {str(rec.get('_kernel_sources_sha'))[:12]} / {rec.get('_popularity')}, this tree "
+                                   f"{kernel_sources_sha()[:12]} / {args.popularity}) - re-run scratch/profile_round.sh")
         except Exception:
             traffic = None
     # measured device copy bandwidth (read + write of a 1 GiB fp32 buffer), outside the timed region: the achievable HBM rate
@@ -615,13 +674,21 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(engine.graph, model, feats_g, feats_c, out, cfg)
 
+    try:
+        from scdeepsort_amd import ops as _ops
+        _kb = _ops.tiled_block_rows(-(-min(cfg.hidden, 256) // 4) * 4)
+        if _ops.tiled_kernel_serves(engine.graph.cg, cfg.hidden):
+            generator_desc["shared_pair_share"] = {"cells<-genes": shared_pair_share(engine.graph.cg.tile_plan(_kb)),
+                                                   "genes<-cells": shared_pair_share(engine.graph.gc.tile_plan(_kb))}
+    except Exception as e:                                       # descriptive only
+        generator_desc["shared_pair_share"] = f"unavailable: {e}"
     if rank == 0:
         line = {"metric": "cells embedded/sec (2-layer WGNN fwd)", "value": round(value, 1), "unit": "cells/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4),
                 "higher_is_better": True, "scaling": mode, "vs_baseline": None,
                 "dtype": "f32" if cfg.feature_dtype == torch.float32 else "f32 (fp16-stored input features)", "data": "synthetic",
                 "config": {"workload": workload_string(cfg, total_cells, mode),
-                           "cells_total": total_cells, "cells_this_rank": C,
+                           "generator": generator_desc, "cells_total": total_cells, "cells_this_rank": C,
                            "nnz_per_gpu": per_gpu[0]["nnz"] if per_gpu else roofline["passes"][0]["nnz"],
                            "parallelism": f"cell-shard x{world}", "setup_s": round(t_setup, 1), "device": ident, "communicator": comm,
                            "gemm_selection": gemm_selection, "step_launch": launch_desc, "eager_ms_per_step": eager_ms, "launch_calibration_ms": launch_calibration,

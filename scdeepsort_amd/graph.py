@@ -333,6 +333,26 @@ class AggCsr:
         return t_rowptr, t_slot.contiguous(), t_val.contiguous(), items
 
 
+def sorted_columns(rowptr: torch.Tensor, col: torch.Tensor, raw: torch.Tensor, n_cols: int):
+    """(col, raw) of the CSR with strictly ascending columns inside every row.  Already-sorted input (every producer in this
+    package) costs three element-wise passes and one flag read; otherwise the non-zeros are sorted within their rows."""
+    nnz = col.shape[0]
+    if nnz < 2:
+        return col, raw
+    dev = col.device
+    inside = torch.ones(nnz, dtype=torch.bool, device=dev)          # False at the first non-zero of a row
+    starts = rowptr[:-1].long()
+    inside[starts[starts < nnz]] = False
+    if not bool(((col[1:] <= col[:-1]) & inside[1:]).any()):
+        return col, raw
+    counts = (rowptr[1:] - rowptr[:-1]).long()
+    rows = torch.repeat_interleave(torch.arange(rowptr.shape[0] - 1, device=dev), counts)
+    key, perm = torch.sort(rows * int(n_cols) + col.long())
+    if bool(((key[1:] == key[:-1])).any()):
+        raise ValueError("expression CSR lists a (cell, gene) pair more than once")
+    return col[perm].contiguous(), raw[perm].contiguous()
+
+
 def _normalize_on_device(rowptr: torch.Tensor, raw: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """K4 (``wgnn_normalize_rows``): w <- deg*w/sum(w) per destination, inv_deg = 1/(deg+1)."""
     if raw.device.type != "cuda":
@@ -384,15 +404,28 @@ class CellGeneGraph:
 
     @staticmethod
     def from_device_csr(rowptr: torch.Tensor, col: torch.Tensor, raw: torch.Tensor, num_genes: int,
-                        chunk: Optional[int] = None, support_mask: Optional[torch.Tensor] = None) -> "CellGeneGraph":
+                        chunk: Optional[int] = None, support_mask: Optional[torch.Tensor] = None,
+                        check_sorted: bool = True) -> "CellGeneGraph":
         """Build from a device CSR of the (cells x genes) raw expression.  ``support_mask`` (bool [cells], default all
         True): only support cells feed the genes; test cells of a predict graph get gene->cell edges only
-        (preprocess.py:126-134,184-187)."""
+        (preprocess.py:126-134,184-187).
+
+        Precondition of the tile plans (``build_tile_plan`` -> ``wgnn_tile_plan_count`` / ``_fill`` walk a row's non-zeros
+        in column order): gene ids ASCENDING and unique inside every cell.  Checked here on the device
+        (``sorted_columns``): an unsorted CSR is sorted within its rows, a repeated (cell, gene) pair is an error - the
+        reference adds one edge pair per non-zero of the expression matrix (preprocess_internal.py:158-173).
+        ``check_sorted=False`` skips the check for producers that guarantee the order."""
         dev = col.device
         C_ = rowptr.shape[0] - 1
+        if col.shape[0] >= 2 ** 31:                        # the operand's offsets are int32 (same guard as from_expression)
+            raise ValueError("nnz >= 2^31: shard the cell axis (sharded.ShardedWgnn)")
+        if raw.shape[0] != col.shape[0]:
+            raise ValueError(f"col has {col.shape[0]} entries, raw {raw.shape[0]}")
         rowptr = rowptr.to(torch.int32).contiguous()
         col = col.to(torch.int32).contiguous()
         raw = raw.to(torch.float32).contiguous()
+        if check_sorted:
+            col, raw = sorted_columns(rowptr, col, raw, num_genes)
         val, inv_deg = _normalize_on_device(rowptr, raw)
         host = rowptr.cpu().numpy()
         cg = AggCsr(rowptr, col, val, inv_deg, C_, num_genes, build_plan(host, chunk, device=dev), host)
@@ -690,6 +723,10 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
     every per-block barrier, so it is dealt as k "virtual rows" - its non-zeros round-robin, i.e. evenly inside every
     source block - that land in different waves (and tiles); each writes a partial sum that ``agg_finalize`` folds in
     fixed order, exactly like the partial sums of column splits.
+
+    Precondition: the columns of every row of ``csr`` ascend (the device plan walk binary-searches a row and takes wave minima
+    of the pending columns).  ``CellGeneGraph.from_device_csr`` establishes it for caller-supplied CSRs (``sorted_columns``);
+    the transposes, sampled blocks and shards built in this package keep it by construction.
 
     ``n_col_splits=None``: heuristic geometry (``auto_tile_geometry`` on the number of virtual rows).
     ``geom``: GEOM_FLAT (16 waves x 16 rows) or GEOM_TALL (8 waves x 49 rows, no dedicated loader waves)."""

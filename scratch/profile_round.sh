@@ -47,7 +47,12 @@ def hbm(key):
     return int((2 * r.get("FETCH_SIZE", 0) + r.get("WRITE_SIZE", 0)) * 1024) if r else None
 tiled = sorted((k for k in res if k.startswith("agg_tiled_flat4")), key=lambda k: int(k.split("=")[1][:-1]))
 fin = sorted((k for k in res if k.startswith("agg_finalize")), key=lambda k: int(k.split("=")[1][:-1]))
-traffic = {"_captured": f"round {tag}, scratch/profile_round.sh: separate rocprofv3 --pmc passes over scratch/one_kernel.py (cfg3 operands, D = 256); "
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+from bench import kernel_sources_sha
+popularity = os.environ.get("WGNN_SYNTH_POPULARITY", "testis199")
+traffic = {"_kernel_sources_sha": kernel_sources_sha(), "_popularity": popularity,
+           "_commit": os.environ.get("WGNN_COMMIT", "stamped when copied into profiles/ (scratch/stamp_traffic.py)"),
+           "_captured": f"round {tag}, scratch/profile_round.sh: separate rocprofv3 --pmc passes over scratch/one_kernel.py (cfg3 operands, D = 256); "
                         "FETCH_SIZE doubled (gfx950 reports half of wide coalesced reads), WRITE_SIZE as reported",
            "_kernels": {k: res[k] for k in tiled + fin}}
 # the launch with the bigger grid-x is the cells<-genes pass when no column split is used; identify by WRITE_SIZE instead:

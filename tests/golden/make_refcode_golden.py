@@ -1,6 +1,6 @@
 """Golden vectors produced by EXECUTING THE REFERENCE'S OWN CODE for the hot path - run in the BUILD container only:
 
-    python tests/golden/make_refcode_golden.py        ->  tests/golden/refcode_{train,predict,1layer}.npz
+    python tests/golden/make_refcode_golden.py        ->  tests/golden/refcode_{train,predict,1layer,wide}.npz
 
 What runs verbatim from /root/reference (imported at generation time, never copied, never shipped):
   * models/gnn.py        : GNN.__init__, GNN.message_func (alpha-index cascade, multiply order), GNN.forward,
@@ -134,7 +134,7 @@ def build_edges(expr, support_mask):
     return src.astype(np.int64), dst.astype(np.int64), wt, node_id
 
 
-def make_case(name, gnn_mod, pre_mod, expr, support_mask, dim, hidden, n_classes, n_layers, seed):
+def make_case(name, gnn_mod, pre_mod, expr, support_mask, dim, hidden, n_classes, n_layers, seed, batch_grads=True):
     C, G = expr.shape
     N = G + C
     src, dst, raw, node_id = build_edges(expr, support_mask)
@@ -170,8 +170,9 @@ def make_case(name, gnn_mod, pre_mod, expr, support_mask, dim, hidden, n_classes
                n_layers=n_layers, feats=feats, seeds=seeds, logits=logits,
                edge_src=src, edge_dst=dst, edge_w_raw=raw, edge_w_norm=w_norm,
                batch=batch, labels=labels, loss=float(loss))
-    for k, p in model.named_parameters():
-        out["grad." + k] = p.grad.numpy().copy()
+    if batch_grads:                       # (the wide case keeps the full-batch set only: the .npz stays under 1 MB)
+        for k, p in model.named_parameters():
+            out["grad." + k] = p.grad.numpy().copy()
     # round 4: the FULL-batch step (every cell a seed, in node order) - the shape of BASELINE cfg4's training step, which the
     # product runs through its fused backward glue (wgnn_agg_bwd_prepare) and loss kernel; own label stream, drawn last so
     # that everything above is unchanged
@@ -194,7 +195,13 @@ def main():
     gnn_mod = load(REF / "models" / "gnn.py", "ref_gnn")
     pre_mod = load(REF / "utils" / "preprocess_internal.py", "ref_preprocess_internal")
     rng = np.random.default_rng(2024)
-    for name, C, G, test_cells, L in (("refcode_train", 14, 9, 0, 2), ("refcode_predict", 17, 11, 5, 2), ("refcode_1layer", 10, 7, 3, 1)):
+    for name, C, G, test_cells, L, dims in (("refcode_train", 14, 9, 0, 2, (12, 8, 4)), ("refcode_predict", 17, 11, 5, 2, (12, 8, 4)),
+                                           ("refcode_1layer", 10, 7, 3, 1, (12, 8, 4)),
+                                           # round 6: wide enough for the LDS-streamed tile kernels at their headline width
+                                           # (aggregated rows of 256 floats = agg_tiled_flat4's D = 256 instantiation; the tiny
+                                           # cases above only reach the row-wave kernel or padded tiles).  Drawn last: the three
+                                           # fixtures above stay bit-identical.
+                                           ("refcode_wide", 300, 200, 60, 2, (64, 256, 8))):
         mask = rng.random((C, G)) < 0.35
         mask[:, 0] = True                 # a hub gene
         mask[2, :] = False                # a cell expressing nothing
@@ -203,8 +210,8 @@ def main():
         support = np.ones(C, bool)
         if test_cells:
             support[-test_cells:] = False
-        make_case(name, gnn_mod, pre_mod, expr, support, dim=12, hidden=8, n_classes=4, n_layers=L, seed=C * 100 + G)
-
+        make_case(name, gnn_mod, pre_mod, expr, support, dim=dims[0], hidden=dims[1], n_classes=dims[2], n_layers=L, seed=C * 100 + G,
+                  batch_grads=name != "refcode_wide")
 
 if __name__ == "__main__":
     main()

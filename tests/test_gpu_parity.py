@@ -2598,3 +2598,141 @@ def test_sharded_branch_with_three_layers(tiled, monkeypatch):
     for k, p in m.named_parameters():
         scale = max(1.0, want_g[k].abs().max().item())
         assert (p.grad - want_g[k]).abs().max().item() < 3e-4 * scale, k
+
+
+# ---- round 6 ------------------------------------------------------------------------------------------------------------------
+def _oracle_graph_from_raw(rp, col, val, G):
+    """The oracle's operand built on the HOST from the raw expression CSR: both directions normalised by the C oracle
+    (preprocess_internal.py:17-23), independent of the device's K4 / transpose."""
+    from oracle import c_oracle as CO
+    C = rp.shape[0] - 1
+    X = sp.csr_matrix((val.cpu().numpy(), col.cpu().numpy(), rp.cpu().numpy()), shape=(C, G))
+    A_cg = X.copy(); A_cg.data = CO.normalize_rows(X.indptr, X.data)
+    XT = sp.csr_matrix(X.T); XT.sort_indices()
+    A_gc = XT.copy(); A_gc.data = CO.normalize_rows(XT.indptr, XT.data)
+    return O.CsrGraph(G, C, A_cg, A_gc, np.diff(A_cg.indptr) + 1, np.diff(A_gc.indptr) + 1)
+
+
+def _forward_vs_oracle(name, oracle_forward):
+    from scdeepsort_amd import ops, synthetic as S
+    cfg = S.CONFIGS[name]
+    G, C = cfg.genes, cfg.cells
+    rp, col, val = S.synth_expression(C, G, cfg.density, device=DEV)
+    g = sda.CellGeneGraph.from_device_csr(rp, col, val, G)
+    torch.manual_seed(1234)
+    m = sda.GNN(cfg.dense_dim, cfg.hidden, cfg.n_classes, cfg.n_layers, G, activation=F.relu).to(DEV).eval()
+    with torch.no_grad():
+        m.alpha.uniform_(0.5, 1.5)
+    feats = S.synth_features(G + C, cfg.dense_dim, device=DEV)
+    ops.PROFILE = []
+    with torch.no_grad():
+        got = m(g, feats)
+    torch.cuda.synchronize()
+    kernels = {dict(zip(t[::2], t[1::2]))["kernel"] for t, _, _ in ops.PROFILE}
+    ops.PROFILE = None
+    assert "agg_tiled_flat4" in kernels, kernels                      # the dominant kernel is what is being compared
+    ocg = _oracle_graph_from_raw(rp, col, val, G)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    want = oracle_forward(sd, ocg, feats.cpu().numpy(), cfg.n_layers)
+    err = float(np.abs(got.cpu().numpy() - want).max())
+    print(f"{name}: full-size forward, max |logits - oracle| over {C} x {cfg.n_classes} = {err:.3e}")
+    assert got.shape == (C, cfg.n_classes) and err < TOL, err
+
+
+def test_full_size_cfg3_forward_matches_the_oracle_on_every_logit():
+    """BASELINE cfg3 at FULL size (100 000 x 20 000, hidden 256, 2 layers, SURVEY 8d's generator) - the bench
+    workload through the bench's kernels - compared with the C oracle (reference multiply order, aggregate-first, its own
+    normalisation of the raw values) on ALL 100 000 x 16 logits at the north_star tolerance."""
+    from oracle import c_oracle as CO
+    _forward_vs_oracle("cfg3", CO.forward)
+
+
+def test_full_size_cfg2_forward_matches_the_python_oracle_on_every_logit():
+    """BASELINE cfg2 (10 000 x 5 000, hidden 128) at full size against oracle.wgnn_oracle.csr_forward (the restatement pinned to
+    the executed reference code, tests/test_oracle.py)."""
+    _forward_vs_oracle("cfg2", lambda sd, ocg, feats, L: O.csr_forward(sd, ocg, feats, L))
+
+
+@pytest.mark.parametrize("order", ["project_first", "auto"])
+def test_tile_kernels_at_headline_width_match_executed_reference_code(order, monkeypatch):
+    """`refcode_wide` (300 cells x 200 genes, 60 test cells, dense_dim 64, hidden 256; logits computed by the
+    reference's OWN gnn.py + normalize_weight, tests/golden/make_refcode_golden.py) drives the LDS-streamed kernel at the width
+    of the bench - agg_tiled_flat4's D = 256 instantiation is compared with executed reference code, not only with the oracle.
+    The operand is far below the size at which a pass is routed to the tile kernels by default, so the routing threshold (the
+    public knob WGNN_TILED_MIN_WORK / ops.TILED_MIN_WORK) is lowered; the profile proves which kernel produced the logits."""
+    from scdeepsort_amd import ops
+    z = np.load(GOLDEN / "refcode_wide.npz")
+    sd = {k[len("param."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param.")}
+    expr = sp.csr_matrix(z["expr"]); G = expr.shape[1]
+    g = sda.CellGeneGraph.from_expression(expr, z["support_mask"], device=DEV)
+    monkeypatch.setattr(ops, "TILED_MIN_WORK", 1)
+    m = make_model(sd, int(z["dim"]), int(z["hidden"]), int(z["n_classes"]), int(z["n_layers"]), G, order)
+    ops.PROFILE = []
+    try:
+        with torch.no_grad():
+            got = m(g, dev(z["feats"]), seeds=torch.from_numpy(z["seeds"]).to(DEV)).cpu().numpy()
+        torch.cuda.synchronize()
+        launches = [dict(zip(t[::2], t[1::2])) for t, _, _ in ops.PROFILE]
+    finally:
+        ops.PROFILE = None
+    wide = [l for l in launches if l["kernel"] == "agg_tiled_flat4" and int(l["D"]) == 256]
+    assert len(wide) >= (3 if order == "project_first" else 1), launches
+    assert not [l for l in launches if l["kernel"] == "agg_main"], launches           # no pass fell back to the row-wave kernel
+    np.testing.assert_allclose(got, z["logits"], atol=TOL)
+    print("refcode_wide", order, "max |logits - reference code| =", float(np.abs(got - z["logits"]).max()))
+
+
+@pytest.mark.parametrize("order", ["auto", "project_first"])
+def test_tile_backward_at_headline_width_matches_executed_reference_code(order, monkeypatch):
+    """The full-batch training step of `refcode_wide` on the LDS-streamed route (K1t forward at D = 256, `wgnn_ce_sum_fwd_bwd`,
+    K2t backward) against the loss and gradients autograd produced through the reference's own `GNN.forward` (`fullgrad.*`)."""
+    from scdeepsort_amd import ops
+    z = np.load(GOLDEN / "refcode_wide.npz")
+    sd = {k[len("param."):]: torch.from_numpy(z[k]) for k in z.files if k.startswith("param.")}
+    expr = sp.csr_matrix(z["expr"]); G = expr.shape[1]
+    g = sda.CellGeneGraph.from_expression(expr, z["support_mask"], device=DEV)
+    monkeypatch.setattr(ops, "TILED_MIN_WORK", 1)
+    m = make_model(sd, int(z["dim"]), int(z["hidden"]), int(z["n_classes"]), int(z["n_layers"]), G, order).train()
+    ops.PROFILE = []
+    try:
+        loss = sda.cross_entropy_sum(m(g, dev(z["feats"])), torch.from_numpy(z["full_labels"]).to(DEV))
+        loss.backward()
+        torch.cuda.synchronize()
+        kernels = {dict(zip(t[::2], t[1::2]))["kernel"] for t, _, _ in ops.PROFILE}
+    finally:
+        ops.PROFILE = None
+    assert "agg_tiled_flat4" in kernels, kernels
+    assert abs(float(loss) - float(z["full_loss"])) < 1e-4 * max(1.0, abs(float(z["full_loss"])))
+    for k, p in m.named_parameters():
+        ref = z["fullgrad." + k]
+        np.testing.assert_allclose(p.grad.cpu().numpy(), ref, atol=TOL * max(1.0, float(np.abs(ref).max())), err_msg=k)
+
+
+def test_unsorted_device_csr_gives_the_sorted_result():
+    """the device plan walk needs ascending columns; `from_device_csr` sorts an unsorted caller CSR within its
+    rows, so the tile kernels give the same logits as for the sorted operand (and a repeated (cell, gene) pair is an error)."""
+    from scdeepsort_amd import ops, synthetic as S
+    C, G, H = 3000, 700, 64
+    rp, col, val = S.synth_expression(C, G, 0.1, seed=3, device=DEV)
+    perm = torch.argsort(torch.rand(col.shape[0], device=DEV))                     # shuffle inside rows: sort by (row, random)
+    rows = torch.repeat_interleave(torch.arange(C, device=DEV), (rp[1:] - rp[:-1]))
+    perm = perm[torch.sort(rows[perm], stable=True).indices]
+    ucol, uval = col[perm].contiguous(), val[perm].contiguous()
+    assert not torch.equal(ucol, col)
+    g_sorted = sda.CellGeneGraph.from_device_csr(rp, col, val, G)
+    g_unsorted = sda.CellGeneGraph.from_device_csr(rp, ucol, uval, G)
+    assert torch.equal(g_unsorted.cg.col, g_sorted.cg.col) and torch.equal(g_unsorted.cg.val, g_sorted.cg.val)
+    alpha = torch.rand(G + 2, device=DEV) + 0.5
+    hg, hc = S.synth_features(G, H, device=DEV), S.synth_features(C, H, seed=3, device=DEV)
+    saved, ops.TILED_MIN_WORK = ops.TILED_MIN_WORK, 1
+    try:
+        a = sda.agg_fwd(g_sorted.cg, alpha, sda.SRC_IS_GENE, G + 1, hg, hc)
+        b = sda.agg_fwd(g_unsorted.cg, alpha, sda.SRC_IS_GENE, G + 1, hg, hc)
+        a2 = sda.agg_fwd(g_sorted.gc, alpha, sda.DST_IS_GENE, G, hc, hg)
+        b2 = sda.agg_fwd(g_unsorted.gc, alpha, sda.DST_IS_GENE, G, hc, hg)
+    finally:
+        ops.TILED_MIN_WORK = saved
+    assert torch.equal(a, b) and torch.equal(a2, b2)
+    dup_col = col.clone(); dup_col[1] = dup_col[0]
+    with pytest.raises(ValueError, match="more than once"):
+        sda.CellGeneGraph.from_device_csr(rp, dup_col, val, G)

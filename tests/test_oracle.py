@@ -177,7 +177,7 @@ def _load_refcode(name):
     return z, sd
 
 
-@pytest.mark.parametrize("name", ["refcode_train", "refcode_predict", "refcode_1layer"])
+@pytest.mark.parametrize("name", ["refcode_train", "refcode_predict", "refcode_1layer", "refcode_wide"])
 def test_restatement_matches_executed_reference_code(name):
     """GNN.forward / message_func / NodeUpdate (gnn.py:10-68) and normalize_weight (preprocess_internal.py:15-23) were
     EXECUTED from the reference tree over a stand-in for DGL's NodeFlow / fn.mean; both formulations of the oracle must
@@ -212,7 +212,7 @@ def test_gradient_oracle_matches_executed_reference_code(name):
         np.testing.assert_allclose(gval.numpy(), z["grad." + k], atol=3e-6, rtol=1e-5, err_msg=k)
 
 
-@pytest.mark.parametrize("name", ["refcode_train", "refcode_predict", "refcode_1layer"])
+@pytest.mark.parametrize("name", ["refcode_train", "refcode_predict", "refcode_1layer", "refcode_wide"])
 def test_full_batch_gradient_oracle_matches_executed_reference_code(name):
     """Round 4: the FULL-batch step (every cell a seed: BASELINE cfg4's shape) through the reference's own GNN code + autograd,
     against the oracle - the fixture the GPU test of the fused backward glue / loss kernel is pinned to."""
