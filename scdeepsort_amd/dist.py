@@ -147,6 +147,109 @@ def all_reduce_sum(x: torch.Tensor) -> torch.Tensor:
     return _AllReduceSum.apply(x) if comm_active() else x
 
 
+# Test / profiling aid: when a list, the split all-reduce appends "ar_fwd_issue" / "ar_fwd_wait" / "ar_bwd_issue" / "ar_bwd_wait"
+# as they happen (tests/test_dist_gloo.py proves the order around the overlapped pass; the GPU timeline test reads it too).
+TRACE: Optional[list] = None
+
+
+def _trace(what: str) -> None:
+    if TRACE is not None:
+        TRACE.append(what)
+
+
+class _AllReduceBegin(torch.autograd.Function):
+    """First half of the SPLIT differentiable SUM all-reduce (round 6): forward issues the collective asynchronously on a copy
+    and returns the in-flight tensor (not to be read before ``_AllReduceEnd``); backward completes the all-reduce of the
+    upstream gradient that ``_AllReduceEnd.backward`` put in flight."""
+
+    @staticmethod
+    def forward(ctx, x, box):
+        ctx.box = box
+        y = x.clone()
+        box["fwd"] = dist.all_reduce(y, op=dist.ReduceOp.SUM, async_op=True)
+        _trace("ar_fwd_issue")
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        work = ctx.box.pop("bwd", None)
+        if work is not None:
+            work.wait()                                 # stream-level dependency on GPU backends, no host sync
+        _trace("ar_bwd_wait")
+        return g, None
+
+
+class _AllReduceEnd(torch.autograd.Function):
+    """Second half: forward waits for the collective; backward issues the all-reduce of the gradient asynchronously.  The two
+    halves bracket the work that overlaps the collective: whatever is recorded BETWEEN them in the forward (the rank's own
+    cells<-genes pass) has its backward node scheduled between ``End.backward`` and ``Begin.backward`` (autograd runs ready
+    nodes latest-created first), i.e. under the all-reduce of dH1_g."""
+
+    @staticmethod
+    def forward(ctx, y, box):
+        ctx.box = box
+        work = box.pop("fwd", None)
+        if work is not None:
+            work.wait()
+        _trace("ar_fwd_wait")
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous().clone()
+        ctx.box["bwd"] = dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True)
+        _trace("ar_bwd_issue")
+        return g, None
+
+
+def all_reduce_sum_begin(x: torch.Tensor):
+    """Split form of :func:`all_reduce_sum`: returns ``(pending, finish)``; the collective is in flight until ``finish(pending)``
+    returns the summed tensor.  Both directions overlap whatever the caller does in between (forward: that work itself;
+    backward: its backward)."""
+    if not comm_active():
+        return x, (lambda y: y)
+    box = {}
+    return _AllReduceBegin.apply(x, box), (lambda y: _AllReduceEnd.apply(y, box))
+
+
+class GradBucket:
+    """ONE pre-allocated flat buffer that every parameter's ``.grad`` is a view of (X1, SURVEY 8e: ~0.8 MB at cfg3 incl.
+    alpha[G+2]): autograd accumulates into the views in place, the SUM all-reduce of the step is one call on ``flat`` - no
+    ``cat`` before it, no per-tensor ``copy_`` after it - and the optimizer reads the views."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no parameter requires a gradient")
+        dt, dev = self.params[0].dtype, self.params[0].device
+        if any(p.dtype != dt or p.device != dev for p in self.params):
+            raise ValueError("GradBucket: parameters of one dtype on one device")
+        self.flat = torch.zeros(sum(p.numel() for p in self.params), dtype=dt, device=dev)
+        self.views, off = [], 0
+        for p in self.params:
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+
+    def matches(self, params) -> bool:
+        ps = [p for p in params if p.requires_grad]
+        return len(ps) == len(self.params) and all(a is b for a, b in zip(ps, self.params))
+
+    def zero(self) -> None:
+        """``optimizer.zero_grad()`` for bucketed parameters: one memset; (re-)attaches the views as ``.grad``."""
+        self.flat.zero_()
+        for p, v in zip(self.params, self.views):
+            if p.grad is not v:
+                p.grad = v
+
+    def all_reduce(self) -> None:
+        for p, v in zip(self.params, self.views):        # a hook / optimizer replaced a .grad: fold it back in (not expected)
+            if p.grad is not v and p.grad is not None:
+                v.copy_(p.grad)
+                p.grad = v
+        if comm_active():
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+
+
 @dataclass
 class LocalOps:
     """Local arithmetic of one shard (bound to the HIP operators in production)."""
@@ -225,8 +328,13 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
             break
         part = ops.genes_partial(p_c)
         if torch.is_grad_enabled() and part.requires_grad:
-            new_c = ops.cells_layer(p_g, p_c, b, relu) if rows is None else ops.cells_layer(p_g, p_c, b, relu, rows, False)
-            part = all_reduce_sum(part)                 # differentiable: backward all-reduces dH1_g
+            # training: the same overlap, differentiable (round 6).  Forward: the [G, H] all-reduce is issued BEFORE this rank's
+            # cells<-genes pass and completed after it; backward: the all-reduce of dH1_g is issued when the gradient of the
+            # summed gene rows is known and completed after the backward of that cells<-genes pass (K2t), see _AllReduceEnd.
+            part, finish = all_reduce_sum_begin(part)
+            with (ops.overlapped() if (comm_active() and ops.overlapped is not None) else contextlib.nullcontext()):
+                new_c = ops.cells_layer(p_g, p_c, b, relu) if rows is None else ops.cells_layer(p_g, p_c, b, relu, rows, False)
+            part = finish(part)
         else:
             # the ONE data-path collective (X2) runs on the communicator's stream while this rank's
             # cells<-genes pass (row-independent, no communication) computes
@@ -273,8 +381,12 @@ def sharded_forward(weights, alpha_unused, feats_g: torch.Tensor, feats_c_local:
     return (logits, None) if async_gather else logits
 
 
-def all_reduce_grads(params) -> None:
-    """X1: SUM all-reduce of parameter gradients in one flat bucket (~0.8 MB at cfg3)."""
+def all_reduce_grads(params, bucket: Optional[GradBucket] = None) -> None:
+    """X1: SUM all-reduce of parameter gradients in one flat bucket (~0.8 MB at cfg3).  With a :class:`GradBucket` the
+    gradients already live in the flat buffer (one collective call, nothing else); without one they are packed and unpacked."""
+    if bucket is not None:
+        bucket.all_reduce()
+        return
     if not comm_active():
         return
     grads = [p.grad for p in params if p.grad is not None]
@@ -287,6 +399,18 @@ def all_reduce_grads(params) -> None:
         n = g.numel()
         g.copy_(flat[off:off + n].view_as(g))
         off += n
+
+
+def grad_bucket_of(optimizer, params) -> GradBucket:
+    """The step's gradient bucket, created once per (optimizer, parameter list) and kept on the optimizer object."""
+    b = getattr(optimizer, "_wgnn_grad_bucket", None)
+    if b is None or not b.matches(params):
+        b = GradBucket(params)
+        try:
+            optimizer._wgnn_grad_bucket = b
+        except AttributeError:
+            pass
+    return b
 
 
 def sharded_train_step(params, weights_fn, feats_g, feats_c_local, labels_local, ops: LocalOps, n_layers: int,
@@ -304,9 +428,10 @@ def sharded_train_step(params, weights_fn, feats_g, feats_c_local, labels_local,
                              dropout_masks=dropout_masks, relu=relu, linear=linear, seeds_local=seeds_local)
     loss = loss_sum(logits, labels_local) if loss_sum is not None else \
         torch.nn.functional.cross_entropy(logits, labels_local, reduction="sum")     # train.py:36
-    optimizer.zero_grad()
+    bucket = grad_bucket_of(optimizer, params)          # .grad of every parameter = a view of ONE flat buffer
+    bucket.zero()                                       # (optimizer.zero_grad() would drop the views)
     loss.backward()
-    all_reduce_grads(params)
+    all_reduce_grads(params, bucket)
     optimizer.step()
     total = loss.detach().clone()
     all_reduce_sum_(total)

@@ -195,6 +195,46 @@ def _worker(rank, world, port, out_dir, cells=90):
         for k, p_ in params.items():
             np.testing.assert_allclose(p_.grad.numpy(), grads_ref[k].numpy(), atol=1e-6, rtol=1e-4, err_msg=k)   # fp32-normalised graph weights in the oracle
 
+        # round 6: the gradients live in ONE flat bucket (views), and the differentiable [G, H] all-reduce is SPLIT around the
+        # rank's own cells<-genes pass in both directions: forward issue -> cells pass -> wait; backward issue (dH1_g) ->
+        # backward of that cells pass -> wait.  A logging autograd Function stands in for the pass.
+        bucket = opt._wgnn_grad_bucket
+        assert all(p_.grad.data_ptr() == v.data_ptr() and p_.grad.shape == v.shape for p_, v in zip(bucket.params, bucket.views))
+        assert bucket.flat.numel() == sum(p_.numel() for p_ in params.values())
+        events = []
+
+        class LogPass(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x):
+                events.append("cells_fwd")
+                return x.view_as(x)
+
+            @staticmethod
+            def backward(ctx, g):
+                events.append("cells_bwd")
+                return g
+        tops_log = D.LocalOps(lambda p_g, p_c, b, relu, rows=None, sc=False: LogPass.apply(tops.cells_layer(p_g, p_c, b, relu)),
+                              tops.genes_partial, tops.genes_finish)
+        D.TRACE = events
+        try:
+            total_l = D.sharded_train_step(list(params.values()), wfn, feats[:G], feats[G + lo:G + hi], labels[lo:hi], tops_log, 2, opt)
+        finally:
+            D.TRACE = None
+        # (the last layer's cells pass logs too: forward after the wait, backward before the backward issue)
+        assert events == ["ar_fwd_issue", "cells_fwd", "ar_fwd_wait", "cells_fwd",
+                          "cells_bwd", "ar_bwd_issue", "cells_bwd", "ar_bwd_wait"], events
+        assert abs(total_l - total) < 1e-9 * max(1.0, abs(total))
+        assert opt._wgnn_grad_bucket is bucket                                  # created once, reused
+        for k, p_ in params.items():
+            np.testing.assert_allclose(p_.grad.numpy(), grads_ref[k].numpy(), atol=1e-6, rtol=1e-4, err_msg=k + " (split all-reduce)")
+        # the synchronous differentiable all-reduce stays available and agrees
+        xs = torch.full((3,), float(rank + 1), dtype=torch.float64, requires_grad=True)
+        ys, fin = D.all_reduce_sum_begin(xs * 2.0)
+        (fin(ys) * torch.arange(3.0, dtype=torch.float64)).sum().backward()
+        want_sum = 2.0 * sum(r + 1 for r in range(world))
+        assert torch.equal(fin(ys).detach(), torch.full((3,), want_sum, dtype=torch.float64)) or world == 1
+        np.testing.assert_allclose(xs.grad.numpy(), 2.0 * world * np.arange(3.0))
+
         # round 4: the same step with the LAST layer in the reference's literal order (`cells_mean_linear`, also in training):
         # same loss, same all-reduced gradients
         def tcml(h_g, h_c, W, b, relu, rows=None, sc=False, prescaled=False):

@@ -103,7 +103,14 @@ def _worker(rank, world, port, out_dir, hidden, dropout, backend=BACKEND, force=
             masks = [(fm[:G].to(dev), fm[G + lo:G + hi].to(dev)) for fm in full]
             if Hp != hidden:                                    # carried zero-padded: the pad columns are 0 anyway
                 masks[1] = tuple(F.pad(x, (0, Hp - hidden), value=1.0) for x in masks[1])
+        D.TRACE = []
         total = eng.train_step(feats[:G], feats[G + lo:G + hi], labels[lo:hi], opt, dropout_masks=masks)
+        trace, D.TRACE = D.TRACE, None
+        # round 6: the differentiable [G, H] all-reduce is split around the rank's own cells<-genes pass, forward and backward
+        # (issue, overlapped pass, wait); the parameter gradients live in ONE flat bucket that is all-reduced in place
+        assert trace == ["ar_fwd_issue", "ar_fwd_wait", "ar_bwd_issue", "ar_bwd_wait"], trace
+        bucket = opt._wgnn_grad_bucket
+        assert all(p_.grad.data_ptr() == v.data_ptr() for p_, v in zip(bucket.params, bucket.views))
         rg = O.build_reference_graph(expr)
         p64 = {k: v.detach().clone().double().requires_grad_(True) for k, v in sd.items()}
         logits = O.nodeflow_forward(p64, rg, feats.cpu().double(), np.arange(G, G + C), 2,
