@@ -1174,7 +1174,7 @@ def test_full_size_cfg4_eight_virtual_ranks_training_gradients_match_unsharded()
                                                   global_stats=stats)))
     bar, parts, box, tl = threading.Barrier(N), [None] * N, {}, threading.local()
 
-    def rendezvous_sum(x):                                  # stands in for dist.all_reduce_sum (differentiable SUM all-reduce)
+    def rendezvous_sum(x):                                  # stands in for the differentiable SUM all-reduce of dist.sharded_forward
         parts[tl.rank] = x
         if bar.wait() == 0:
             tot = parts[0]
@@ -1198,7 +1198,9 @@ def test_full_size_cfg4_eight_virtual_ranks_training_gradients_match_unsharded()
             errors.append(ex)
             bar.abort()
 
-    saved, D.all_reduce_sum = D.all_reduce_sum, rendezvous_sum
+    met = []
+    # (round 6: the training branch issues the all-reduce in two halves around the cells<-genes pass: all_reduce_sum_begin)
+    saved, D.all_reduce_sum_begin = D.all_reduce_sum_begin, lambda x: (met.append(1), (rendezvous_sum(x), lambda y: y))[1]
     try:
         threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(N)]
         for t in threads:
@@ -1206,8 +1208,9 @@ def test_full_size_cfg4_eight_virtual_ranks_training_gradients_match_unsharded()
         for t in threads:
             t.join()
     finally:
-        D.all_reduce_sum = saved
+        D.all_reduce_sum_begin = saved
     assert not errors, errors
+    assert len(met) == N, met                               # every virtual rank went through the (stand-in) collective
     loss = losses[0]
     for q in losses[1:]:
         loss = loss + q
