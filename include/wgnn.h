@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define WGNN_VERSION 204           /* 0.2.x - INCOMPATIBLE with 0.1.x binders: `neigh_sum` was inserted before `n_out` in
+#define WGNN_VERSION 205           /* 0.2.x - INCOMPATIBLE with 0.1.x binders: `neigh_sum` was inserted before `n_out` in
                                       wgnn_agg_fwd / wgnn_agg_fwd_tiled (0.1.1, should have been a major bump then - a 0.1.0
                                       caller would pass n_out in a pointer slot); 0.2.0 adds int64 row pointers
                                       (WGNN_FLAG_ROWPTR_I64, wgnn_normalize_rows_i64), WGNN_FLAG_SRC_PRESCALED and
@@ -53,7 +53,11 @@ extern "C" {
                                       need >= 202).  0.2.3: wgnn_agg_bwd_prepare, wgnn_ce_sum_fwd_bwd; wgnn_agg_bwd_src_tiled
                                       takes col_scale == NULL (pre-scaled gradient rows).  0.2.4: WGNN_PLAN_TALL (tall tile
                                       plans: 8 waves x 49 rows),
-                                      wgnn_tile_plan_count / wgnn_tile_plan_fill. */
+                                      wgnn_tile_plan_count / wgnn_tile_plan_fill.  0.2.5: a tile-plan segment with an odd number
+                                      of entries is ALWAYS padded to even (0.2.4: only when shared pairs follow), so its size
+                                      depends on its entry count alone: wgnn_tile_plan_count no longer reports pair counts
+                                      (`seg_pairs` is ignored, may be NULL) and wgnn_tile_plan_fill takes the padded offsets;
+                                      the aggregation kernels read either layout. */
 
 /* Tile-plan geometry, OR-ed into the `block_rows` argument of wgnn_agg_fwd_tiled / wgnn_agg_bwd_src_tiled /
  * wgnn_agg_bwd_alpha_tiled (0.2.4; an older library rejects the bit with WGNN_ERR_PLAN): the plan was built for the TALL tile -
@@ -377,13 +381,16 @@ int wgnn_ce_sum_fwd_bwd(const float* logits, int64_t ld_logits, const int64_t* l
                         void* stream);
 
 /* ---------------------------------------------------------------------------
- * Tile-plan construction on the device (0.2.4).  `entries` / `seg_ptr` of a tile plan (see wgnn_agg_fwd_tiled) from the CSR
- * and the row -> (tile, wave, slot) assignment, without a sort: one wavefront per (tile, wave) walks its <= 64 destination rows
- * (their non-zeros are sorted by column) in lock step through the tile's source range.  Two passes over the same arguments:
- *   wgnn_tile_plan_count : seg_total[s] = entries of segment s, seg_pairs[s] = those that pair up on a source row
- *                          (s = (tile * nblk_max + block) * waves + wave; arrays zero-initialised by the caller)
- *   caller               : seg_ptr = exclusive prefix sum of seg_total + pad, pad = (seg_total - seg_pairs) odd && seg_pairs > 0
- *   wgnn_tile_plan_fill  : entries[seg_ptr[s] ..) = [unshared][pad][shared pairs] of every segment
+ * Tile-plan construction on the device (0.2.4, revised 0.2.5).  `entries` / `seg_ptr` of a tile plan (see wgnn_agg_fwd_tiled) from
+ * the CSR and the row -> (tile, wave, slot) assignment, without a sort: one wavefront per (tile, wave), lane = destination slot,
+ * steps through its <= 64 destination rows (their non-zeros are sorted by column) along the tile's source range.  Two passes:
+ *   wgnn_tile_plan_count : seg_total[s] = entries of segment s  (s = (tile * nblk_max + block) * waves + wave; array
+ *                          zero-initialised by the caller; every lane counts along its own row, no group walk)
+ *   caller               : seg_ptr = exclusive prefix sum of seg_total + (seg_total & 1)   [n_seg + 1 offsets]
+ *   wgnn_tile_plan_fill  : entries[seg_ptr[s] .. seg_ptr[s + 1]) = [unshared][pad, iff the count is odd][shared pairs]: the walk in
+ *                          lock step (wave minimum of the pending columns -> ballot = the group on that source row) writes the
+ *                          unshared entries upwards from the segment's start and the pairs downwards from its end
+ *   seg_pairs : ignored since 0.2.5 (may be NULL)
  *   slot_vrow : int32[n_row_tiles * waves * rpw]   virtual row of (row tile, wave, slot) | -1
  *   vrow_*    : per virtual row: CSR row, part j, parts k  (the row's non-zeros j, j + k, j + 2k, ...; k = 1: the whole row)
  *   flat_t    : int32[n_tiles]  row tile of the tile launched at position f;  tile_hdr as in wgnn_agg_fwd_tiled

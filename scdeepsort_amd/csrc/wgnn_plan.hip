@@ -8,8 +8,13 @@
 // sorted by column, so ONE wavefront per (tile, wave) - lane = destination slot - walks its rows in lock step through
 // the tile's source range: per LDS block it repeatedly takes the smallest pending column (a wave minimum), finds the lanes
 // that hold it (a ballot = the group of entries on that source row), and knows every entry's place in the segment from
-// running counts.  Two passes of the same walk: COUNT (entries / paired entries per segment) and, after a prefix sum over the
-// segments, FILL.  No atomics, deterministic.  Reference counterpart: none (DGL built its own CSR, preprocess_internal.py:215).
+// running counts.  Round 6: the COUNT pass no longer walks groups.  A segment is padded to an EVEN number of entries whenever its
+// entry count is odd (the pair count is even, so "odd unshared run" == "odd total": the pad costs no pair step, an odd chunk has
+// an idle half step anyway), which makes a segment's size a function of its entry count alone - and that needs only every
+// lane stepping through ITS row once per block (no wave minimum, no ballot): ~10x fewer instructions than the group walk.  FILL
+// (after the prefix sum over the segments) places the unshared entries from the segment's start upwards and the shared pairs
+// from its end DOWNWARDS, so it needs no pair count either; the pad lands between them.
+// No atomics, deterministic.  Reference counterpart: none (DGL built its own CSR, preprocess_internal.py:215).
 #include <climits>
 #include "wgnn_common.h"
 
@@ -27,8 +32,8 @@ struct PlanArgs {
     const int2* tile_hdr;                       // [n_flat] {col_begin, col_end}
     int n_flat, waves, rpw, nblk_max, kb;
     int nsplit;                                 // wavefronts per (tile, wave): each walks 1/nsplit of the tile's blocks
-    int* seg_total; int* seg_pairs;             // [n_flat * nblk_max * waves]  COUNT: written; FILL: read
-    const int* seg_ptr; int2* entries;          // FILL
+    int* seg_total;                             // [n_flat * nblk_max * waves]  COUNT: written
+    const int* seg_ptr; int2* entries;          // FILL: [n_seg + 1] offsets (prefix sum of seg_total rounded up to even), output
 };
 
 // Minimum over the 64 lanes, on the VALU's data-parallel primitives (row shifts inside a row of 16, then the row broadcasts of
@@ -41,6 +46,17 @@ __device__ __forceinline__ int wave_min(int v) {
     v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x118, 0xf, 0xf, false));     // row_shr:8  -> lane 15 of a row: its minimum
     v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x142, 0xa, 0xf, false));     // row_bcast:15 into rows 1 and 3
     v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x143, 0xc, 0xf, false));     // row_bcast:31 into rows 2 and 3
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
+// Sum over the 64 lanes, same data-parallel primitives (a row-wise inclusive scan, then the row broadcasts).
+__device__ __forceinline__ int wave_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);     // row_shr:8  -> lane 15 of a row: its sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
     return __builtin_amdgcn_readlane(v, 63);
 }
 
@@ -83,54 +99,50 @@ __global__ void __launch_bounds__(kPlanWavesPerBlock * 64) tile_plan_walk(const 
     for (int b = b_begin; b < b_end; ++b) {
         const int lo_col = cb + b * a.kb, hi_col = min(ce, lo_col + a.kb);
         const size_t seg = ((size_t)f * a.nblk_max + b) * a.waves + w;
-        int tot = 0, prs = 0, out_un = 0, out_sh = 0, p0 = 0, n_un = 0, last_un = 0;
-        bool pad = false;
-        if (FILL) {
-            p0 = a.seg_ptr[seg];
-            const int n_pr = a.seg_pairs[seg];
-            n_un = a.seg_total[seg] - n_pr;
-            pad = (n_un & 1) && n_pr > 0;
-            out_un = p0;
-            out_sh = p0 + n_un + (pad ? 1 : 0);
+        if (!FILL) {
+            // COUNT: my row's entries in this block; lanes run their own number of steps (a handful), one sum per block
+            int cnt = 0;
+            while (c0 < hi_col) {
+                ++cnt; ++j;
+                c0 = c1; c1 = c2; c2 = c3;
+                c3 = colat(j + 3);
+            }
+            const int tot = wave_sum(cnt);
+            if (lane == 0) a.seg_total[seg] = tot;
+            continue;
         }
+        const int p0 = a.seg_ptr[seg];
+        int out_un = p0, out_sh = a.seg_ptr[seg + 1], last_un = 0;          // unshared upwards, pairs downwards
         for (;;) {
             const int s = wave_min(c0 < hi_col ? c0 : INT_MAX);             // the smallest pending source row of this block
             if (s == INT_MAX) break;
             const bool match = c0 == s;
             const unsigned long long M = __ballot(match);                   // the destination slots that read it: one group
             const int g = __popcll(M), p = g & ~1;                          // p of them pair up, an odd one stays unshared
-            if (FILL) {
-                if (match) {
-                    const int r = __popcll(M & ((1ull << lane) - 1ull));    // my rank in the group (slots ascending)
-                    const int wbits = __float_as_int(a.val[base + (long)j * stride]);
-                    int meta = (lane << 8) | (s - lo_col);
-                    if (r < p) {
-                        meta |= kPairFlag;
-                        if ((r & 1) == 0) meta |= (lane + 1 + __builtin_ctzll(M >> (lane + 1))) << 16;   // the second's slot
-                        a.entries[out_sh + r] = make_int2(meta, wbits);
-                    } else {
-                        a.entries[out_un] = make_int2(meta, wbits);
-                    }
-                }
-                if (g & 1) {
-                    last_un = ((63 - __builtin_clzll(M)) << 8) | (s - lo_col);
-                    ++out_un;
-                }
-                out_sh += p;
-            } else {
-                tot += g; prs += p;
-            }
+            out_sh -= p;
             if (match) {
+                const int r = __popcll(M & ((1ull << lane) - 1ull));        // my rank in the group (slots ascending)
+                const int wbits = __float_as_int(a.val[base + (long)j * stride]);
+                int meta = (lane << 8) | (s - lo_col);
+                if (r < p) {
+                    meta |= kPairFlag;
+                    if ((r & 1) == 0) meta |= (lane + 1 + __builtin_ctzll(M >> (lane + 1))) << 16;   // the second's slot
+                    a.entries[out_sh + r] = make_int2(meta, wbits);
+                } else {
+                    a.entries[out_un] = make_int2(meta, wbits);
+                }
                 ++j;
                 c0 = c1; c1 = c2; c2 = c3;
                 c3 = colat(j + 3);
             }
+            if (g & 1) {
+                last_un = ((63 - __builtin_clzll(M)) << 8) | (s - lo_col);
+                ++out_un;
+            }
         }
-        if (FILL) {
-            if (pad && lane == 0) a.entries[p0 + n_un] = make_int2((last_un & 0xFFFF) | kPadFlag, 0);   // zero-weight filler
-        } else if (lane == 0) {
-            a.seg_total[seg] = tot; a.seg_pairs[seg] = prs;
-        }
+        // an odd segment: one slot is left between the unshared run and the pairs - the zero-weight filler (a copy of the entry
+        // before it; every odd segment has an unshared entry, the pair count being even)
+        if (out_un < out_sh && lane == 0) a.entries[out_un] = make_int2((last_un & 0xFFFF) | kPadFlag, 0);
     }
 }
 
@@ -145,10 +157,10 @@ int pick_nsplit(long n_tile_waves, int nblk_max) {
 
 int check(const PlanArgs& a) {
     if (!a.rowptr || !a.col || !a.slot_vrow || !a.vrow_row || !a.vrow_part || !a.vrow_k || !a.flat_t || !a.tile_hdr ||
-        !a.seg_total || !a.seg_pairs)
+        !a.seg_total)
         return WGNN_ERR_BAD_ARG;
-    if (a.n_flat < 0 || a.waves < 1 || a.waves > 16 || a.rpw < 1 || a.rpw > 64 || a.nblk_max < 1 || a.kb < 1 || a.kb > 255 ||
-        a.nsplit < 1)
+    const bool geom_ok = (a.waves == 16 && a.rpw == 16) || (a.waves == 8 && a.rpw == 49);   // the two plan geometries (6-bit slots)
+    if (a.n_flat < 0 || !geom_ok || a.nblk_max < 1 || a.kb < 16 || a.kb > 255 || a.nsplit < 1)
         return WGNN_ERR_BAD_ARG;
     return WGNN_OK;
 }
@@ -159,9 +171,10 @@ extern "C" int wgnn_tile_plan_count(const int32_t* rowptr, const int32_t* col, c
                                     const int32_t* vrow_row, const int32_t* vrow_part, const int32_t* vrow_k,
                                     const int32_t* flat_t, const int32_t* tile_hdr, int64_t n_flat, int32_t waves, int32_t rpw,
                                     int32_t nblk_max, int32_t block_rows, int32_t* seg_total, int32_t* seg_pairs, void* stream) {
+    (void)seg_pairs;                                   // (0.2.4 wrote the paired entries per segment here; unused since 0.2.5)
+    if (n_flat < 0 || n_flat > INT_MAX / 256) return n_flat < 0 ? WGNN_ERR_BAD_ARG : WGNN_ERR_UNSUPPORTED;
     PlanArgs a{rowptr, col, nullptr, slot_vrow, vrow_row, vrow_part, vrow_k, flat_t, reinterpret_cast<const int2*>(tile_hdr),
-               (int)n_flat, waves, rpw, nblk_max, block_rows, 1, seg_total, seg_pairs, nullptr, nullptr};
-    if (n_flat > INT_MAX / 256) return WGNN_ERR_UNSUPPORTED;
+               (int)n_flat, waves, rpw, nblk_max, block_rows, 1, seg_total, nullptr, nullptr};
     a.nsplit = pick_nsplit((long)n_flat * waves, nblk_max);
     if (int rc = check(a)) return rc;
     if (n_flat == 0) return WGNN_OK;
@@ -176,10 +189,11 @@ extern "C" int wgnn_tile_plan_fill(const int32_t* rowptr, const int32_t* col, co
                                    const int32_t* flat_t, const int32_t* tile_hdr, int64_t n_flat, int32_t waves, int32_t rpw,
                                    int32_t nblk_max, int32_t block_rows, const int32_t* seg_total, const int32_t* seg_pairs,
                                    const int32_t* seg_ptr, int32_t* entries, void* stream) {
+    (void)seg_pairs;
+    if (n_flat < 0 || n_flat > INT_MAX / 256) return n_flat < 0 ? WGNN_ERR_BAD_ARG : WGNN_ERR_UNSUPPORTED;
     PlanArgs a{rowptr, col, val, slot_vrow, vrow_row, vrow_part, vrow_k, flat_t, reinterpret_cast<const int2*>(tile_hdr),
-               (int)n_flat, waves, rpw, nblk_max, block_rows, 1, const_cast<int32_t*>(seg_total), const_cast<int32_t*>(seg_pairs),
+               (int)n_flat, waves, rpw, nblk_max, block_rows, 1, const_cast<int32_t*>(seg_total),
                seg_ptr, reinterpret_cast<int2*>(entries)};
-    if (n_flat > INT_MAX / 256) return WGNN_ERR_UNSUPPORTED;
     a.nsplit = pick_nsplit((long)n_flat * waves, nblk_max);
     if (int rc = check(a)) return rc;
     if (!val || !seg_ptr || !entries) return WGNN_ERR_BAD_ARG;

@@ -538,7 +538,7 @@ def _pair_segment_entries(seg: torch.Tensor, meta: torch.Tensor, val_bits: torch
 
     Two entries of a segment that read the SAME source row (one gene drawn by two of the wave's 16 cells; one cell
     expressing two of the wave's genes) form a shared pair: the kernel stages that LDS row once for both.  A segment is
-    laid out as [unshared entries][pad to an even count, if pairs follow][shared pairs], so that a pair always starts at an even offset
+    laid out as [unshared entries][pad, iff the entry count is odd][shared pairs], so that a pair always starts at an even offset
     (chunks of 64 never cut one) and the pairs are the LAST pair steps of a right-aligned chunk.  Meta word:
         unshared / second of a pair : slot << 8 | src_local                    (second: | TILE_PAIR_FLAG)
         first of a pair             : TILE_PAIR_FLAG | slot_of_second << 16 | slot << 8 | src_local
@@ -589,7 +589,9 @@ def _pair_segment_entries(seg: torch.Tensor, meta: torch.Tensor, val_bits: torch
     del sh
     base_sh = cs_sh[bounds[:-1]].long()
     n_sh = cs_sh[bounds[1:]].long() - base_sh
-    pad = ((n_all - n_sh) & 1) * (n_sh > 0).long()                        # only where pairs follow the unshared run
+    pad = (n_all - n_sh) & 1                                              # an odd segment is padded to even (ABI 0.2.5; the pair
+                                                                          # count is even, so this is n_all & 1: a segment's size
+                                                                          # follows from its entry count alone - csrc/wgnn_plan.hip)
     seg_ptr = torch.zeros(n_seg + 1, dtype=torch.int64, device=dev)
     torch.cumsum(n_all + pad, 0, out=seg_ptr[1:])
     # position = seg_ptr[s] + (unshared: entries of s in front of me that are unshared | shared: all unshared of s + pad + shared
@@ -846,22 +848,20 @@ def build_tile_plan(csr: AggCsr, n_row_tiles: Optional[int] = None, n_col_splits
         flat_t[flat_of.reshape(-1)] = torch.arange(n_row_tiles, device=dev, dtype=torch.int32).repeat(n_col_splits)
         hdr_c = hdr.contiguous()
         seg_total = torch.zeros(n_seg, dtype=torch.int32, device=dev)
-        seg_pairs = torch.zeros(n_seg, dtype=torch.int32, device=dev)
         rowptr_c, col_c, val_c = csr.rowptr.contiguous(), csr.col.contiguous(), csr.val.contiguous()
         common = (_ptr(slot_vrow), _ptr(vrow32), _ptr(vpart32), _ptr(vk32), _ptr(flat_t), _ptr(hdr_c), n_flat, TILE_WAVES,
                   TILE_ROWS // TILE_WAVES, nblk_max, blk)
-        _lib.check(_lib.call(dev, "wgnn_tile_plan_count", _ptr(rowptr_c), _ptr(col_c), *common, _ptr(seg_total), _ptr(seg_pairs),
+        _lib.check(_lib.call(dev, "wgnn_tile_plan_count", _ptr(rowptr_c), _ptr(col_c), *common, _ptr(seg_total), None,
                              _stream(dev)), "wgnn_tile_plan_count")
-        pad = ((seg_total - seg_pairs) & 1) * (seg_pairs > 0)
         seg_ptr = torch.zeros(n_seg + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(seg_total + pad, 0, out=seg_ptr[1:])
+        torch.cumsum(seg_total + (seg_total & 1), 0, out=seg_ptr[1:])        # an odd segment is padded to even (ABI 0.2.5)
         n_entries = int(seg_ptr[-1])
         if n_entries >= 2 ** 31 - 1:
             raise ValueError("tile plan with >= 2^31 entries: shard the operand")
         seg_ptr32 = seg_ptr.to(torch.int32)
         entries = torch.empty((n_entries, 2), dtype=torch.int32, device=dev)
         _lib.check(_lib.call(dev, "wgnn_tile_plan_fill", _ptr(rowptr_c), _ptr(col_c), _ptr(val_c), *common, _ptr(seg_total),
-                             _ptr(seg_pairs), _ptr(seg_ptr32), _ptr(entries), _stream(dev)), "wgnn_tile_plan_fill")
+                             None, _ptr(seg_ptr32), _ptr(entries), _stream(dev)), "wgnn_tile_plan_fill")
         return TilePlan(items.contiguous(), hdr_c, long_rows, n_part,
                         n_row_tiles, n_col_splits, n_loaders, entries, seg_ptr32, nblk_max, block_rows, geom)
     tile_v = torch.empty(V, dtype=torch.int64, device=dev); tile_v[order] = tile

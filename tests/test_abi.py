@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in wgnn.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in _lib.py"
-    assert lib.wgnn_version() == 204 and lib.wgnn_version() >= _lib.ABI_MIN
+    assert lib.wgnn_version() == 205 and lib.wgnn_version() >= _lib.ABI_MIN
     assert b"ok" == lib.wgnn_last_error_string(0)
 
 
