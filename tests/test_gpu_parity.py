@@ -1099,9 +1099,14 @@ def test_hipgraph_replay_with_seeds_and_graphed_train_step():
 
 def test_full_size_cfg3_training_step_matches_cpu_autograd():
     """BASELINE cfg3/cfg4 at FULL size: one training step (2-layer forward through the tiled kernels, CE-sum loss,
-    backward through K2t/K3t) against an independent CPU evaluation - torch.sparse CSR matmuls + torch autograd in fp32
-    over the same normalised operand.  Loss to 1e-5 relative; every parameter gradient to 2e-3 of its own max
-    (fp32 sums over up to 1e5 terms in two different orders); alpha checked on all 20,002 entries."""
+    backward through K2t/K3t) against an independent CPU evaluation - torch.sparse CSR matmuls + torch autograd in FP64
+    over the same normalised operand (round 6: an fp32 reference carries its own summation error of the size being tested).
+    Loss to 1e-6 relative; every parameter gradient to 4 x the error observed on the MI355X
+    (printed below; fp32 sums over up to 1e5 terms); alpha checked on all 20,002 entries."""
+    # observed on the MI355X (round 6, SURVEY 8d's graph): alpha 1.3e-4 (row dots of mixed sign: cancellation), layers.0 weight 1.8e-5,
+    # every other parameter <= 2.4e-6
+    GRAD_TOL = {"alpha": 6e-4}
+    GRAD_TOL_DEFAULT = 8e-5
     from scdeepsort_amd import synthetic as S
     cfg = S.CONFIGS["cfg3"]
     G, C = cfg.genes, cfg.cells
@@ -1118,12 +1123,12 @@ def test_full_size_cfg3_training_step_matches_cpu_autograd():
     assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in m.parameters())
     # ---- CPU oracle: same math with torch sparse CSR + autograd
     def tcsr(d, shape):
-        return torch.sparse_csr_tensor(d.rowptr.long().cpu(), d.col.long().cpu(), d.val.cpu(), size=shape)
+        return torch.sparse_csr_tensor(d.rowptr.long().cpu(), d.col.long().cpu(), d.val.cpu().double(), size=shape)
     A_cg, A_gc = tcsr(g.cg, (C, G)), tcsr(g.gc, (G, C))
-    inv_c, inv_g = g.cg.inv_deg.cpu().unsqueeze(1), g.gc.inv_deg.cpu().unsqueeze(1)
-    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in m.named_parameters()}
+    inv_c, inv_g = g.cg.inv_deg.cpu().double().unsqueeze(1), g.gc.inv_deg.cpu().double().unsqueeze(1)
+    p = {k: v.detach().cpu().double().clone().requires_grad_(True) for k, v in m.named_parameters()}
     a = p["alpha"].reshape(-1)
-    h_g, h_c = feats[:G].cpu(), feats[G:].cpu()
+    h_g, h_c = feats[:G].cpu().double(), feats[G:].cpu().double()
     for i in range(2):
         W, b = p[f"layers.{i}.fc_neigh.weight"], p[f"layers.{i}.fc_neigh.bias"]
         p_g, p_c = F.linear(h_g, W), F.linear(h_c, W)
@@ -1133,11 +1138,16 @@ def test_full_size_cfg3_training_step_matches_cpu_autograd():
         h_c = n_c
     ref = F.cross_entropy(F.linear(h_c, p["linear.weight"], p["linear.bias"]), labels.cpu(), reduction="sum")
     ref.backward()
-    assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref)), (float(loss), float(ref))
+    print(f"full-size cfg3 step: loss {float(loss):.4f} vs fp64 {float(ref):.4f} (rel {abs(float(loss) - float(ref)) / abs(float(ref)):.2e})")
+    assert abs(float(loss) - float(ref)) < 1e-6 * abs(float(ref)), (float(loss), float(ref))
+    worst = 0.0
     for k, q in m.named_parameters():
-        want, got = p[k].grad.numpy(), q.grad.cpu().numpy()
+        want, got = p[k].grad.numpy(), q.grad.cpu().double().numpy()
         scale = np.abs(want).max()
-        assert np.abs(got - want).max() < 2e-3 * scale + 1e-6, (k, np.abs(got - want).max(), scale)
+        rel = np.abs(got - want).max() / scale
+        worst = max(worst, rel)
+        print(f"   grad {k}: max |err| / max |grad| = {rel:.2e}")
+        assert rel < GRAD_TOL.get(k, GRAD_TOL_DEFAULT), (k, rel)
 
 
 def test_full_size_cfg4_eight_virtual_ranks_training_gradients_match_unsharded():
