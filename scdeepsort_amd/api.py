@@ -135,8 +135,10 @@ class BundlePaths:
     * ``flat`` - all four files in ``root`` (what ``fit(save_path=...)`` of the documented package example produces when it is
       handed a plain directory, docs/api.rst:120-130).
 
-    ``layout="auto"``: reading picks the layout whose checkpoint exists (reference first); writing picks ``reference`` when
-    ``root`` is named ``pretrained`` or already holds a ``{species}/`` or ``models/`` subtree, else ``flat``."""
+    ``layout="auto"`` is deterministic: a bundle of this (species, tissue) that already exists under ``root``
+    decides - its layout is kept, for reading and for re-fitting in place; BOTH layouts present is an error (pass the layout).
+    With nothing there yet, writing takes ``reference`` iff ``root`` is named ``pretrained`` (the reference tree's own name),
+    else ``flat``; reading falls back to ``flat`` (and the caller reports the missing file)."""
 
     def __init__(self, root, species: str, tissue: str, layout: str = "auto", for_write: bool = False):
         root = Path(root)
@@ -145,10 +147,14 @@ class BundlePaths:
         ref_base = root if (root / "models").is_dir() and not (root / species).is_dir() else root / species
         pt_name = f"{species}-{tissue}.pt"
         if layout == "auto":
-            if for_write:
-                layout = "reference" if (root.name == "pretrained" or (root / species).is_dir() or (root / "models").is_dir()) else "flat"
+            has_ref, has_flat = (ref_base / "models" / pt_name).exists(), (root / pt_name).exists()
+            if has_ref and has_flat:
+                raise ValueError(f"{root} holds {pt_name} in BOTH bundle layouts ({ref_base / 'models' / pt_name} and "
+                                 f"{root / pt_name}): pass bundle_layout='reference' or 'flat'")
+            if has_ref or has_flat:
+                layout = "reference" if has_ref else "flat"
             else:
-                layout = "reference" if (ref_base / "models" / pt_name).exists() else "flat"
+                layout = "reference" if (for_write and root.name == "pretrained") else "flat"
         self.layout, self.root = layout, root
         if layout == "reference":
             self.model = ref_base / "models" / pt_name

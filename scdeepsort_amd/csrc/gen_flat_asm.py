@@ -76,11 +76,6 @@ def acc(k):
     return f"v[{M['acc'] + k}:{M['acc'] + k + 1}]"
 
 
-def L(name):
-    """Label with the map's prefix (both pipelines may be instantiated in one translation unit)."""
-    return name.replace("Lw4_", f"L{M['label']}_")
-
-
 FMA2 = "fma2" in ABLATE          # v_fma_f32 x4 instead of v_pk_fma_f32 x2 per entry (a REAL variant: results stay correct)
 WRL = "wrl" in ABLATE            # experiment: weights through v_readlane into SGPR pairs instead of the LDS strip
 SCR = 92                         # scratch SGPR of the computed branch

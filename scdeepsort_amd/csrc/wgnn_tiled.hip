@@ -57,7 +57,7 @@ struct TArgs {
     const int2* tile_hdr;     // [n_tiles] {col_begin, col_end}
     int nblk_max;
     int kb;                   // source rows per LDS block
-    int tall;                 // plan geometry: 0 = 16 waves x 16 rows per tile, 1 = 8 waves x 50 rows (WGNN_PLAN_TALL)
+    int tall;                 // plan geometry: 0 = 16 waves x 16 rows per tile, 1 = 8 waves x 49 rows (WGNN_PLAN_TALL)
 };
 
 // out[r] = scale[r] * in[r]   (alpha folded into the source table; tiny: |table| bytes)
@@ -179,7 +179,7 @@ __global__ void __launch_bounds__(kTW * 64) agg_tiled(const KArgs a, const TArgs
     }
 }
 
-// Epilogue shared by the two geometries of the flat tile kernel (16 waves x 16 rows, 8 waves x 50 rows): turns the wave's
+// Epilogue shared by the two geometries of the flat tile kernel (16 waves x 16 rows, 8 waves x 49 rows): turns the wave's
 // accumulator rows into the kernel's outputs.  `items_base` = first item of this wave (tile * rows per tile + wave * RPW),
 // `acc_row(i)` copies accumulator row i of the wave into compiler registers (literal-register asm of the caller).
 template <typename TOut, int EPI, int RPW, typename AccRow>
@@ -626,7 +626,7 @@ agg_tiled_tall(const KArgs a, const TArgs t) {
     const unsigned dbg = DBG ? a.flags : 0u;
     const bool do_fill = !(dbg & kDbgNoFill), do_comp = !(dbg & kDbgNoCompute), do_barrier = !(dbg & kDbgNoBarrier);
 
-    for (int r = 0; r < kTallRPW; ++r)                   // zero the accumulators v[60:259]
+    for (int r = 0; r < kTallRPW; ++r)                   // zero the accumulators v[60:255]
         asm volatile("s_set_gpr_idx_on %0, gpr_idx(DST)\n\tv_mov_b32 v60, 0\n\tv_mov_b32 v61, 0\n\t"
                      "v_mov_b32 v62, 0\n\tv_mov_b32 v63, 0\n\ts_set_gpr_idx_off" ::"s"(r * 4) : WGNN_TALL_CLOB);
 

@@ -239,7 +239,10 @@ class AggCsr:
         """Lazily built plan for the LDS-streamed kernel (heuristic tile geometry, see build_tile_plan), cached per
         LDS block height and number of dedicated loader waves (``loaders=None``: the module default).  The backward entries
         K2t / K3t (``ops.agg_bwd_src`` / ``agg_bwd_alpha``) use the SAME default: they read the loader waves and shared pairs
-        off the plan like the forward, and were measured that way (training step 10.7 -> 10.1 -> 9.9 ms in round 3)."""
+        off the plan like the forward, and were measured that way (training step 10.7 -> 10.1 -> 9.9 ms in round 3).
+        The tall geometry (opt-in, ``TILE_TALL``) exists for the flat kernel family only - every width the tile route serves
+        (``ops.tiled_kernel_serves``: D <= 256); the library's A/B flag that forces the generic kernel answers a tall plan with
+        WGNN_ERR_PLAN."""
         if self._tile_plan is None:
             self._tile_plan = {}
         tall = TILE_SHARED_PAIRS and (TILE_TALL == "on" or (TILE_TALL == "auto" and self.n_rows >= TALL_MIN_ROWS))

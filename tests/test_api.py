@@ -171,6 +171,19 @@ def test_bundle_paths_resolve_both_layouts(tmp_path):
     assert BundlePaths(root, "mouse", "Testis").label_map() == tmp_path / "map" / "celltype2subtype.xlsx"
     with pytest.raises(ValueError):
         BundlePaths(root, "mouse", "Testis", layout="tree")
+    # the choice is deterministic.  An existing bundle keeps its layout on a re-fit (a flat bundle inside a directory
+    # that has grown a models/ subtree stays flat; the reference tree stays the reference tree) ...
+    fdir = tmp_path / "model_save_path"
+    fdir.mkdir(); (fdir / "mouse-Testis.pt").write_bytes(b"x"); (fdir / "models").mkdir()
+    assert BundlePaths(fdir, "mouse", "Testis", for_write=True).layout == "flat"
+    assert BundlePaths(root, "mouse", "Testis", for_write=True).layout == "reference"
+    # ... a species directory handed over before it holds anything is a plain directory, not half a reference tree ...
+    assert BundlePaths(tmp_path / "pretrained2" / "human", "human", "Lung", for_write=True).layout == "flat"
+    # ... and a root that holds the checkpoint in BOTH layouts is refused instead of one silently shadowing the other
+    (root / "mouse-Testis.pt").write_bytes(b"y")
+    with pytest.raises(ValueError, match="BOTH"):
+        BundlePaths(root, "mouse", "Testis")
+    assert BundlePaths(root, "mouse", "Testis", layout="reference").model == b.model
 
 
 def _handwritten_bundle(tmp_path, layout):
