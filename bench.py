@@ -274,11 +274,17 @@ def build_workload(cfg, mode, rank, world, dev, S, shard_range):
         rp, col, val = S.synth_expression(cfg.cells, G, cfg.density, seed=S.REFERENCE_SEED + rank, device=dev)
         feats_c = S.synth_features(cfg.cells, cfg.dense_dim, seed=100 + rank, device=dev, dtype=cfg.feature_dtype)
         return (rp, col, val), feats_g, feats_c, cfg.cells * world, None
-    rp, col, val = S.synth_expression(cfg.cells, G, cfg.density, seed=S.REFERENCE_SEED, device=dev)
     feats_c = S.synth_features(cfg.cells, cfg.dense_dim, seed=100, device=dev, dtype=cfg.feature_dtype)
     if world == 1:
+        rp, col, val = S.synth_expression(cfg.cells, G, cfg.density, seed=S.REFERENCE_SEED, device=dev)
         return (rp, col, val), feats_g, feats_c, cfg.cells, None
     lo, hi = shard_range(cfg.cells, rank, world)
+    if rank != 0:
+        # the rows lo .. hi-1 of the SAME matrix: only the chunks of the generator that meet the shard are drawn (the host's cores
+        # are shared by the node's ranks; rank 0 draws the whole job once more for the self-check below)
+        mine = S.synth_expression(cfg.cells, G, cfg.density, seed=S.REFERENCE_SEED, device=dev, cell_range=(lo, hi))
+        return mine, feats_g, feats_c[lo:hi].clone(), cfg.cells, None
+    rp, col, val = S.synth_expression(cfg.cells, G, cfg.density, seed=S.REFERENCE_SEED, device=dev)
     b, e = int(rp[lo]), int(rp[hi])
     mine = ((rp[lo:hi + 1] - rp[lo]).clone(), col[b:e].clone(), val[b:e].clone())
     whole = (rp, col, val, feats_c) if rank == 0 else None

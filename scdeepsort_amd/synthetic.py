@@ -26,7 +26,7 @@ import math
 import os
 from concurrent.futures import ThreadPoolExecutor
 from dataclasses import dataclass
-from typing import Tuple
+from typing import Optional, Tuple
 
 import numpy as np
 import torch
@@ -121,11 +121,17 @@ def sampling_weights(genes: int, density: float = 0.04) -> np.ndarray:
 
 
 def _host_threads() -> int:
-    return max(1, min(64, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+    """Generator threads of THIS process: the host's cores shared among the ranks of the node (LOCAL_WORLD_SIZE), <= 64."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1") or 1))
+    return max(1, min(64, cores // ranks))
 
 
 def _synth_expression_numpy(cells: int, genes: int, density: float, seed: int, shuffle_genes: bool,
-                            chunk_cells: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+                            chunk_cells: int, cell_range: Optional[Tuple[int, int]] = None
+                            ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """``cell_range = (lo, hi)``: only the rows lo .. hi-1 of the SAME matrix (a rank's shard of one job): the per-cell counts and
+    the chunks' child streams are drawn for the whole matrix (cheap), the per-(cell, gene) work only for the chunks the range meets."""
     rng = np.random.default_rng(seed)
     mu = math.log(density * genes) - NNZ_LOG_STD ** 2 / 2
     k = np.rint(rng.lognormal(mu, NNZ_LOG_STD, size=cells)).astype(np.int64)
@@ -156,34 +162,48 @@ def _synth_expression_numpy(cells: int, genes: int, density: float, seed: int, s
         val = np.clip(g.normal(3.0, 0.9, size=col.shape[0]), 0.5, 7.0).astype(np.float32)
         return col, val
 
-    nthreads = min(_host_threads(), len(starts))
+    lo, hi = (0, cells) if cell_range is None else (max(0, int(cell_range[0])), min(cells, int(cell_range[1])))
+    wanted = [i for i, c0 in enumerate(starts) if c0 < hi and c0 + chunk_cells > lo]
+    nthreads = min(_host_threads(), len(wanted))
     if nthreads > 1:
         with ThreadPoolExecutor(nthreads) as pool:
-            parts = list(pool.map(chunk, range(len(starts))))
+            parts = list(pool.map(chunk, wanted))
     else:
-        parts = [chunk(i) for i in range(len(starts))]
-    rowptr = np.zeros(cells + 1, dtype=np.int64)
-    np.cumsum(k, out=rowptr[1:])
+        parts = [chunk(i) for i in wanted]
     col = np.concatenate([p[0] for p in parts]) if parts else np.zeros(0, np.int32)
     val = np.concatenate([p[1] for p in parts]) if parts else np.zeros(0, np.float32)
+    if cell_range is not None:                                     # cut the first / last chunk down to the range
+        first = starts[wanted[0]] if wanted else lo
+        kk = k[first:min(cells, (starts[wanted[-1]] + chunk_cells) if wanted else lo)]
+        off = np.zeros(kk.shape[0] + 1, dtype=np.int64); np.cumsum(kk, out=off[1:])
+        col, val = col[off[lo - first]:off[hi - first]], val[off[lo - first]:off[hi - first]]
+        k = k[lo:hi]
+    rowptr = np.zeros(k.shape[0] + 1, dtype=np.int64)
+    np.cumsum(k, out=rowptr[1:])
     return rowptr, col, val
 
 
 def synth_expression(cells: int, genes: int, density: float = 0.04, seed: int = REFERENCE_SEED,
                      device: torch.device | str = "cpu", shuffle_genes: bool = True,
-                     chunk_cells: int | None = None, popularity: str | None = None
-                     ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+                     chunk_cells: int | None = None, popularity: str | None = None,
+                     cell_range: Optional[Tuple[int, int]] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """CSR (rowptr int64 [C+1], col int32 sorted per row, val float32) of a (cells x genes) expression matrix, resident on
     ``device``.  ``popularity``: "testis199" (SURVEY 8d, default; drawn on the host with numpy) or "dense_head" (rounds 1-5);
-    the default can be switched with WGNN_SYNTH_POPULARITY."""
+    the default can be switched with WGNN_SYNTH_POPULARITY.  ``cell_range = (lo, hi)``: the CSR of rows lo .. hi-1 of that matrix
+    only (rowptr re-based to 0) - what one rank of a cell-sharded job needs; identical to slicing the whole matrix."""
     popularity = popularity or os.environ.get("WGNN_SYNTH_POPULARITY", "testis199")
     if popularity == "dense_head":
-        return _synth_expression_dense_head(cells, genes, density, seed, device, shuffle_genes, chunk_cells or 4096)
+        rp, col, val = _synth_expression_dense_head(cells, genes, density, seed, device, shuffle_genes, chunk_cells or 4096)
+        if cell_range is not None:
+            lo, hi = int(cell_range[0]), int(cell_range[1])
+            b, e = int(rp[lo]), int(rp[hi])
+            rp, col, val = (rp[lo:hi + 1] - rp[lo]).clone(), col[b:e].clone(), val[b:e].clone()
+        return rp, col, val
     if popularity != "testis199":
         raise ValueError(f"unknown popularity law {popularity!r} (testis199 | dense_head)")
     if chunk_cells is None:
         chunk_cells = max(16, min(1024, (1 << 24) // max(genes, 1)))   # <= 64 MiB of keys per chunk
-    rowptr, col, val = _synth_expression_numpy(cells, genes, density, seed, shuffle_genes, chunk_cells)
+    rowptr, col, val = _synth_expression_numpy(cells, genes, density, seed, shuffle_genes, chunk_cells, cell_range)
     device = torch.device(device)
     return (torch.from_numpy(rowptr).to(device), torch.from_numpy(col).to(device), torch.from_numpy(val).to(device))
 

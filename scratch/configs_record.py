@@ -1,4 +1,4 @@
-"""Records of the other BASELINE configs -> gpurun_out/r05_configs.json (copied to profiles/):
+"""Records of the other BASELINE configs -> gpurun_out/<WGNN_ROUND_TAG, default r06>_configs.json (copied to profiles/):
   cfg2 forward (hipGraph replay), cfg5 (764,741 cells, fp16-stored features) forward on ONE GPU, cfg4's full-batch training
   step at N = 1, and DeepSortPredictor-shaped inference at atlas scale: a predict graph of 10k support cells + 100k test
   cells over 20k genes, every test cell a seed (predict.py:61-88), the reference's predict-time sizes dense_dim 400 /
@@ -28,6 +28,17 @@ d = json.loads(line[-1]) if line else {"error": se[-800:]}
 if "roofline" in d:
     d["roofline"].pop("note", None)
 out["cfg3_hidden200_forward_1gpu"] = {"cmd": "python bench.py --config cfg3 --hidden 200 --steps 20 --warmup 3 --no-cpu-baseline --no-secondary  (the reference's default hidden_dim, train.py:137)", "wall_s": dt, "line": d}
+# the headline workload under BOTH popularity laws: SURVEY 8d's (the default) and rounds 1-5's dense head
+both = {}
+for pop in ("testis199", "dense_head"):
+    so, se, dt = run([sys.executable, "bench.py", "--popularity", pop, "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-secondary"])
+    line = [l for l in so.splitlines() if l.startswith("{")]
+    d = json.loads(line[-1]) if line else {"error": se[-800:]}
+    both[pop] = {"ms_per_step": d.get("ms_per_step"), "cells_per_s": d.get("value"), "roofline_frac": (d.get("roofline") or {}).get("frac"),
+                 "dominant_launch_ms": (d.get("roofline") or {}).get("avg_launch_ms"),
+                 "passes": [(p["rows"], p["src_rows"], p["avg_ms"]) for p in (d.get("roofline") or {}).get("passes", [])],
+                 "generator": (d.get("config") or {}).get("generator"), "workload": (d.get("config") or {}).get("workload")}
+out["cfg3_both_popularity_laws"] = {"cmd": "python bench.py --popularity {testis199|dense_head} --steps 20 --warmup 3 --no-cpu-baseline --no-secondary", **both}
 so, se, dt = run([sys.executable, "examples/train_sharded.py", "--config", "cfg3", "--steps", "10"])
 out["cfg4_full_batch_training_step_1gpu"] = {"cmd": "python examples/train_sharded.py --config cfg3 --steps 10", "wall_s": dt,
                                              "stdout": so.strip().splitlines()[-1] if so.strip() else se[-800:]}
@@ -72,6 +83,6 @@ for L in (1, 2):
 out["predictor_shaped_inference"] = {"graph": f"{n_sup} support + {n_test} test cells x {G} genes, nnz {g.cg.nnz}, dense_dim 400, hidden 200",
                                       "call": "GNN.forward(graph, feats, seeds = every test cell)  [DeepSortPredictor.predict, predict.py:61-88]", **pred}
 Path(ROOT / "gpurun_out").mkdir(exist_ok=True)
-(ROOT / "gpurun_out" / "r05_configs.json").write_text(json.dumps(out, indent=1))
+(ROOT / "gpurun_out" / (os.environ.get("WGNN_ROUND_TAG", "r06") + "_configs.json")).write_text(json.dumps(out, indent=1))
 print(json.dumps(out["predictor_shaped_inference"], indent=1))
 print({k: (v.get("line", {}).get("ms_per_step"), v.get("stdout")) for k, v in out.items() if isinstance(v, dict) and k != "predictor_shaped_inference"})

@@ -1,7 +1,7 @@
 """Round 4: what ONE rank of the strong-scaling job does at N = 1/2/4/8 - rank 0's shard of the cfg3 graph
 (C/N cells, gene side normalised with the GLOBAL statistics), the sharded branch of the engine without a process group (the
 collectives are skipped, everything else is the production path) - per-kernel HIP-event times, geometry chosen by
-auto_tile_geometry, and the forward time.  -> gpurun_out/r05_shard_sizes.json"""
+auto_tile_geometry, and the forward time.  -> gpurun_out/r06_shard_sizes.json"""
 import json, sys, time, torch, torch.nn.functional as F
 from pathlib import Path
 sys.path.insert(0, '/root/repo')
@@ -10,7 +10,7 @@ from scdeepsort_amd import synthetic as S, ops, dist as D
 from scdeepsort_amd.sharded import ShardedWgnn
 from scdeepsort_amd import tuning
 import os
-OUT = '/root/repo/gpurun_out/' + os.environ.get('WGNN_SHARD_SIZES_OUT', 'r05_shard_sizes.json')
+OUT = '/root/repo/gpurun_out/' + os.environ.get('WGNN_SHARD_SIZES_OUT', 'r06_shard_sizes.json')
 TUNED = os.environ.get('TUNED', '1') == '1' and tuning.use_tuned_gemms()      # tracked per-shape GEMM picks (what bench.py runs with)
 dev = torch.device('cuda:0')
 cfg = S.CONFIGS['cfg3']; G = cfg.genes

@@ -514,3 +514,18 @@ def test_sorted_columns_sorts_within_rows_and_rejects_repeats():
     # descending col across a row boundary is NOT an inversion; an empty operand / single entry is fine
     e = torch.zeros(0, dtype=torch.int32)
     assert sorted_columns(torch.tensor([0, 0], dtype=torch.int32), e, e.float(), 5)[0] is e
+
+
+def test_synthetic_cell_range_is_a_slice_of_the_whole_matrix(monkeypatch):
+    """A rank of a cell-sharded job draws only ITS rows (`cell_range`), bit-identical to slicing the whole matrix - for both
+    popularity laws, ranges that cut chunks, empty and one-row ranges; the generator's thread count follows LOCAL_WORLD_SIZE."""
+    for pop in ("testis199", "dense_head"):
+        rp, col, val = S.synth_expression(1300, 700, seed=4, popularity=pop, chunk_cells=257)
+        for lo, hi in ((0, 1300), (0, 1), (250, 900), (1299, 1300), (514, 514), (257, 514)):
+            a, b, c = S.synth_expression(1300, 700, seed=4, popularity=pop, chunk_cells=257, cell_range=(lo, hi))
+            s, e = int(rp[lo]), int(rp[hi])
+            assert torch.equal(a, rp[lo:hi + 1] - rp[lo]) and torch.equal(b, col[s:e]) and torch.equal(c, val[s:e]), (pop, lo, hi)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    import os
+    cores = len(os.sched_getaffinity(0))
+    assert S._host_threads() == max(1, min(64, cores // 8))
