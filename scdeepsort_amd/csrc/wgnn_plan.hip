@@ -341,6 +341,7 @@ int pick_nsplit(long n_tile_waves, int nblk_max) {
     if (want < 1) want = 1;
     if (want > 16) want = 16;
     if (want > nblk_max) want = nblk_max;
+    if (want < 1) want = 1;                      // (nblk_max < 1 is rejected by check(); never divide by zero before it)
     return (int)want;
 }
 

@@ -70,6 +70,20 @@ def test_argument_validation_returns_error_codes_without_gpu():
     assert lin(fl=2) == -1                       # only WGNN_FLAG_RELU
     assert lin(x=C.c_void_p(8), dt=1, K=0) == -1
     assert lib.wgnn_normalize_rows(one, one, one, None, 0, None) == 0      # empty input is a no-op
+    # tile-plan construction (ABI 0.2.5): the two plan geometries only, 16 <= block_rows <= 255, range check on the tile
+    # count ahead of everything else; seg_pairs is ignored and may be NULL; an empty plan is a no-op
+    def count(n_flat=4, waves=16, rpw=16, nblk=8, kb=78, seg_total=one, rowptr=one):
+        return lib.wgnn_tile_plan_count(rowptr, one, one, one, one, one, one, one, n_flat, waves, rpw, nblk, kb, seg_total, None, None)
+    def fill(n_flat=4, waves=16, rpw=16, nblk=8, kb=78, seg_ptr=one, entries=one, val=one):
+        return lib.wgnn_tile_plan_fill(one, one, val, one, one, one, one, one, one, n_flat, waves, rpw, nblk, kb, one, None, seg_ptr, entries, None)
+    assert count(waves=4) == -1 and count(waves=16, rpw=64) == -1 and count(waves=8, rpw=16) == -1      # not a plan geometry
+    assert count(kb=8) == -1 and count(kb=256) == -1 and count(nblk=0) == -1
+    assert count(seg_total=None) == -1 and count(rowptr=None) == -1
+    assert count(n_flat=-1) == -1 and count(n_flat=2 ** 31) == -3
+    assert count(n_flat=0) == 0 and count(n_flat=0, waves=8, rpw=49) == 0
+    assert fill(waves=5) == -1 and fill(kb=300) == -1 and fill(n_flat=2 ** 31) == -3
+    assert fill(seg_ptr=None) == -1 and fill(entries=None) == -1 and fill(val=None) == -1
+    assert fill(n_flat=0) == 0
     for code in (-1, -2, -3, -4, -5, -6):
         assert len(lib.wgnn_last_error_string(code)) > 3
 
