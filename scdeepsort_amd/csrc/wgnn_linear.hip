@@ -257,6 +257,13 @@ extern "C" int wgnn_linear_wgrad_workspace(int64_t M, int32_t N, int32_t K, int6
     const long tiles = ((N + kBM - 1) / kBM) * ((K + kBN - 1) / kBN);
     long s = (4L * 256 + tiles - 1) / tiles;                 // ~4 workgroups per CU
     s = std::max(1L, std::min(s, (long)((M + 511) / 512)));      // but at least 512 rows per slab
+    // whole rounds of workgroups over the 256 CUs (round 6): tiles x slabs that is not a multiple of 256 leaves a thin last
+    // round - 4 tiles x 196 slabs = 784 workgroups ran as 3 full rounds + 16 stragglers (the 256 x 256 gradient at 0.42 of
+    // the matrix peak), 8 x 40 = 320 as one round + a quarter (20 000 rows: 0.28)
+    long g = tiles, r = 256;
+    while (r) { const long t = g % r; g = r; r = t; }            // gcd(tiles, 256)
+    const long q = 256 / g;                                      // slabs per whole round
+    if (s >= q) s = (s / q) * q;
     *n_slabs = s;
     *bytes = s * (int64_t)N * K * 4;
     return WGNN_OK;
