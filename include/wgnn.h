@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define WGNN_VERSION 205           /* 0.2.x - INCOMPATIBLE with 0.1.x binders: `neigh_sum` was inserted before `n_out` in
+#define WGNN_VERSION 206           /* 0.2.x - INCOMPATIBLE with 0.1.x binders: `neigh_sum` was inserted before `n_out` in
                                       wgnn_agg_fwd / wgnn_agg_fwd_tiled (0.1.1, should have been a major bump then - a 0.1.0
                                       caller would pass n_out in a pointer slot); 0.2.0 adds int64 row pointers
                                       (WGNN_FLAG_ROWPTR_I64, wgnn_normalize_rows_i64), WGNN_FLAG_SRC_PRESCALED and
@@ -57,7 +57,7 @@ extern "C" {
                                       of entries is ALWAYS padded to even (0.2.4: only when shared pairs follow), so its size
                                       depends on its entry count alone: wgnn_tile_plan_count no longer reports pair counts
                                       (`seg_pairs` is ignored, may be NULL) and wgnn_tile_plan_fill takes the padded offsets;
-                                      the aggregation kernels read either layout. */
+                                      the aggregation kernels read either layout.  0.2.6: wgnn_csr_transpose_* (additive). */
 
 /* Tile-plan geometry, OR-ed into the `block_rows` argument of wgnn_agg_fwd_tiled / wgnn_agg_bwd_src_tiled /
  * wgnn_agg_bwd_alpha_tiled (0.2.4; an older library rejects the bit with WGNN_ERR_PLAN): the plan was built for the TALL tile -
@@ -406,6 +406,27 @@ int wgnn_tile_plan_fill(const int32_t* rowptr, const int32_t* col, const float* 
                         const int32_t* flat_t, const int32_t* tile_hdr, int64_t n_tiles, int32_t waves, int32_t rpw,
                         int32_t nblk_max, int32_t block_rows, const int32_t* seg_total, const int32_t* seg_pairs,
                         const int32_t* seg_ptr, int32_t* entries, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Stable CSR transpose on the device (0.2.6): the gene-major copy of the (cells x genes) expression CSR - every stored value
+ * gives a cell->gene AND a gene->cell edge (preprocess_internal.py:170-173), and normalize_weight is per destination (:17-23), so
+ * the genes<-cells direction needs the RAW values re-ordered by gene, cells ascending inside a gene - without a sort: an entry's
+ * place in its gene's row is the number of earlier cells that express the gene (per-chunk LDS histograms, a prefix over the
+ * chunks, then every chunk walks its cells in order).  Deterministic; n_cols <= 32768 (else WGNN_ERR_UNSUPPORTED: the caller
+ * sorts).  Precondition: a row lists a column at most once.
+ *   wgnn_csr_transpose_workspace : n_chunks and the byte size of `counts` (int32 [n_chunks * n_cols]) for an operand
+ *   wgnn_csr_transpose_count     : counts[chunk][col], t_count[col] = entries of column col (rows with row_keep[r] == 0 dropped;
+ *                                  row_keep == NULL keeps every row)
+ *   caller                       : t_rowptr[0] = 0, t_rowptr[c + 1] = t_rowptr[c] + t_count[c]
+ *   wgnn_csr_transpose_fill      : t_col[t_rowptr[c] ..) = the rows that list column c, ascending; t_val their values
+ *                                  (overwrites `counts`)
+ * ------------------------------------------------------------------------- */
+int wgnn_csr_transpose_workspace(int64_t n_rows, int32_t n_cols, int64_t* n_chunks, int64_t* bytes);
+int wgnn_csr_transpose_count(const int32_t* rowptr, const int32_t* col, const uint8_t* row_keep, int64_t n_rows, int32_t n_cols,
+                             int64_t n_chunks, int32_t* counts, int32_t* t_count, void* stream);
+int wgnn_csr_transpose_fill(const int32_t* rowptr, const int32_t* col, const float* val, const uint8_t* row_keep, int64_t n_rows,
+                            int32_t n_cols, int64_t n_chunks, int32_t* counts, const int32_t* t_rowptr, int32_t* t_col, float* t_val,
+                            void* stream);
 
 #ifdef __cplusplus
 }

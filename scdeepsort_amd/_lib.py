@@ -17,7 +17,7 @@ F32, F16 = 0, 1
 PLAN_TALL = 1 << 16                # tile-plan geometry bit OR-ed into `block_rows` (include/wgnn.h WGNN_PLAN_TALL, 0.2.4)
 FLAG_RELU, FLAG_NO_MEAN, FLAG_NO_SELF, FLAG_SELF_COMPACT, FLAG_ROWPTR_I64, FLAG_SRC_PRESCALED, FLAG_OUT_SCALE_ALPHA = 1, 2, 4, 8, 16, 32, 64
 ABI_MAJOR = 2                      # include/wgnn.h WGNN_VERSION / 100
-ABI_MIN = 205                      # 0.2.1: shared-pair marks in tile-plan entries; 0.2.2: WGNN_FLAG_OUT_SCALE_ALPHA (gnn.GNN sets it); 0.2.3: fused training glue; 0.2.5: even-padded plan segments
+ABI_MIN = 206                      # 0.2.1: shared-pair marks in tile-plan entries; 0.2.2: WGNN_FLAG_OUT_SCALE_ALPHA (gnn.GNN sets it); 0.2.3: fused training glue; 0.2.5: even-padded plan segments
 
 _vp, _i32, _i64, _u32, _int = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_int
 
@@ -55,6 +55,9 @@ SIGNATURES = {
     "wgnn_ce_sum_workspace": (C.c_int, [_i64, _vp]),
     "wgnn_ce_sum_fwd_bwd": (C.c_int, [_vp, _i64, _vp, _i64, _i32, _vp, _vp, _i64, _vp, _i64, _vp]),
     "wgnn_tile_plan_count": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "wgnn_csr_transpose_workspace": (C.c_int, [_i64, _i32, _vp, _vp]),
+    "wgnn_csr_transpose_count": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp]),
+    "wgnn_csr_transpose_fill": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp, _vp]),
     "wgnn_tile_plan_fill": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
     "wgnn_agg_linear_relu_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _int, _i32, _vp, _i64, _vp, _i64, _vp, _vp,
                                            _i64, _i32, _u32, _vp, _i64, _vp, _i64, _vp, _i64, _vp,

@@ -12,7 +12,7 @@ from pathlib import Path
 
 PKG = Path(__file__).resolve().parent
 ROOT = PKG.parent
-SRC = [PKG / "csrc" / "wgnn_kernels.hip", PKG / "csrc" / "wgnn_tiled.hip", PKG / "csrc" / "wgnn_linear.hip", PKG / "csrc" / "wgnn_sample.hip", PKG / "csrc" / "wgnn_train.hip", PKG / "csrc" / "wgnn_plan.hip"]
+SRC = [PKG / "csrc" / "wgnn_kernels.hip", PKG / "csrc" / "wgnn_tiled.hip", PKG / "csrc" / "wgnn_linear.hip", PKG / "csrc" / "wgnn_sample.hip", PKG / "csrc" / "wgnn_train.hip", PKG / "csrc" / "wgnn_plan.hip", PKG / "csrc" / "wgnn_transpose.hip"]
 LIB = PKG / "libwgnn_hip.so"
 GEN = PKG / "csrc" / "gen_flat_asm.py"          # writes csrc/wgnn_flat_asm.inc (the hand-scheduled entry pipeline)
 

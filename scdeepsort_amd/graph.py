@@ -215,16 +215,11 @@ class AggCsr:
             self._t._max_row_nnz = max(1, n)
         if self._t is None:
             dev = self.device
-            counts = torch.bincount(self.col.long(), minlength=self.n_cols)
-            t_rowptr = torch.zeros(self.n_cols + 1, dtype=torch.int64, device=dev)
-            torch.cumsum(counts, 0, out=t_rowptr[1:])
-            rows = torch.repeat_interleave(torch.arange(self.n_rows, device=dev, dtype=torch.int32),
-                                           (self.rowptr[1:] - self.rowptr[:-1]).long())
-            # (16-bit keys when the source ids fit: two radix passes instead of four)
-            order = torch.sort(self.col.to(torch.int16) if self.n_cols < 2 ** 15 else self.col, stable=True).indices
-            t_col = rows[order].contiguous()
-            t_val = self.val[order].contiguous()
-            t_rowptr32 = t_rowptr.to(torch.int32)
+            if (CSR_TRANSPOSE_KERNEL and dev.type == "cuda" and 0 < self.n_cols <= 32768 and self.n_rows > 0 and self.ell_cnt is None
+                    and self.rowptr.dtype == torch.int32 and self.col.dtype == torch.int32 and self.val.dtype == torch.float32):
+                t_rowptr32, t_col, t_val = _transpose_on_device(self.rowptr, self.col, self.val, self.n_rows, self.n_cols, None)
+            else:
+                t_rowptr32, t_col, t_val = _transpose_by_sort(self.rowptr, self.col, self.val, self.n_rows, self.n_cols, None)
             if self.rowptr_host is None:             # device-built block: a source feeds at most every row once
                 plan, host = device_plan(t_rowptr32, self.n_cols, max(1, self.n_rows), TRANSPOSE_CHUNK,
                                          nnz_bound=self.nnz), None                  # only hub sources are cut (<= 8 items each)
@@ -357,6 +352,52 @@ def sorted_columns(rowptr: torch.Tensor, col: torch.Tensor, raw: torch.Tensor, n
     return col[perm].contiguous(), raw[perm].contiguous()
 
 
+# The gene-major copy of the operand is built by the library's stable transpose (csrc/wgnn_transpose.hip: per-chunk LDS histograms +
+# an in-order walk, no sort) when the operand lives on a GPU and the gene ids fit its counters; False = the framework path
+# (bincount, stable radix sort, two gathers) - also what CPU operands and > 32768 genes take.
+CSR_TRANSPOSE_KERNEL = __import__("os").environ.get("WGNN_CSR_TRANSPOSE_KERNEL", "1") == "1"
+
+
+def _transpose_by_sort(rowptr, col, raw, n_rows: int, n_cols: int, row_mask: Optional[torch.Tensor]):
+    """(t_rowptr int32 [n_cols + 1], t_col int32, t_raw f32): column-major copy, rows ascending inside a column, rows with
+    ``row_mask == False`` dropped.  Framework primitives."""
+    dev = col.device
+    rows = torch.repeat_interleave(torch.arange(n_rows, device=dev, dtype=torch.int32), (rowptr[1:] - rowptr[:-1]).long())
+    s_col, s_raw = col, raw
+    if row_mask is not None:
+        keep = row_mask.to(dev)[rows.long()]
+        rows, s_col, s_raw = rows[keep], col[keep], raw[keep]
+    counts = torch.bincount(s_col.long(), minlength=n_cols)
+    t_rowptr = torch.zeros(n_cols + 1, dtype=torch.int64, device=dev)
+    torch.cumsum(counts, 0, out=t_rowptr[1:])
+    # radix sort by gene id: 16-bit keys when they fit (two 8-bit passes; 32-bit keys take four, 64-bit ones eight)
+    order = torch.sort(s_col.to(torch.int16) if n_cols < 2 ** 15 else s_col, stable=True).indices
+    return t_rowptr.to(torch.int32), rows[order].contiguous(), s_raw[order].contiguous()
+
+
+def _transpose_on_device(rowptr, col, raw, n_rows: int, n_cols: int, row_mask: Optional[torch.Tensor]):
+    """The same through ``wgnn_csr_transpose_count`` / ``_fill`` (rowptr int32, col int32 - a row lists a column once)."""
+    import ctypes as C
+    dev = col.device
+    nch, nb = C.c_int64(), C.c_int64()
+    _lib.check(_lib.lib().wgnn_csr_transpose_workspace(n_rows, n_cols, C.addressof(nch), C.addressof(nb)), "wgnn_csr_transpose_workspace")
+    counts = torch.empty(nb.value // 4, dtype=torch.int32, device=dev)
+    t_count = torch.empty(n_cols, dtype=torch.int32, device=dev)
+    keep = None if row_mask is None else row_mask.to(device=dev, dtype=torch.uint8).contiguous()
+    if keep is not None and keep.shape[0] != n_rows:
+        raise ValueError(f"support_mask has {keep.shape[0]} entries for {n_rows} cells")
+    _lib.check(_lib.call(dev, "wgnn_csr_transpose_count", _ptr(rowptr), _ptr(col), _ptr(keep), n_rows, n_cols, nch.value,
+                         _ptr(counts), _ptr(t_count), _stream(dev)), "wgnn_csr_transpose_count")
+    t_rowptr = torch.zeros(n_cols + 1, dtype=torch.int32, device=dev)
+    torch.cumsum(t_count, 0, out=t_rowptr[1:])
+    nnz_t = col.shape[0] if keep is None else int(t_rowptr[-1])
+    t_col = torch.empty(nnz_t, dtype=torch.int32, device=dev)
+    t_raw = torch.empty(nnz_t, dtype=torch.float32, device=dev)
+    _lib.check(_lib.call(dev, "wgnn_csr_transpose_fill", _ptr(rowptr), _ptr(col), _ptr(raw), _ptr(keep), n_rows, n_cols, nch.value,
+                         _ptr(counts), _ptr(t_rowptr), _ptr(t_col), _ptr(t_raw), _stream(dev)), "wgnn_csr_transpose_fill")
+    return t_rowptr, t_col, t_raw
+
+
 def _normalize_on_device(rowptr: torch.Tensor, raw: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     """K4 (``wgnn_normalize_rows``): w <- deg*w/sum(w) per destination, inv_deg = 1/(deg+1)."""
     if raw.device.type != "cuda":
@@ -434,20 +475,10 @@ class CellGeneGraph:
         host = rowptr.cpu().numpy()
         cg = AggCsr(rowptr, col, val, inv_deg, C_, num_genes, build_plan(host, chunk, device=dev), host)
         # transpose the RAW values (support cells only), then normalise per gene
-        rows = torch.repeat_interleave(torch.arange(C_, device=dev, dtype=torch.int32), (rowptr[1:] - rowptr[:-1]).long())
-        s_col, s_raw = col, raw
-        if support_mask is not None:
-            keep = support_mask.to(dev)[rows.long()]
-            rows, s_col, s_raw = rows[keep], col[keep], raw[keep]
-        counts = torch.bincount(s_col.long(), minlength=num_genes)
-        t_rowptr = torch.zeros(num_genes + 1, dtype=torch.int64, device=dev)
-        torch.cumsum(counts, 0, out=t_rowptr[1:])
-        # radix sort by gene id: 16-bit keys when they fit (two 8-bit passes; 32-bit keys take four, 64-bit ones eight)
-        order = torch.sort(s_col.to(torch.int16) if num_genes < 2 ** 15 else s_col, stable=True).indices
-        t_col = rows[order].contiguous()
-        t_raw = s_raw[order].contiguous()
-        del rows, order
-        t_rowptr = t_rowptr.to(torch.int32)
+        if CSR_TRANSPOSE_KERNEL and dev.type == "cuda" and 0 < num_genes <= 32768 and C_ > 0:
+            t_rowptr, t_col, t_raw = _transpose_on_device(rowptr, col, raw, C_, num_genes, support_mask)
+        else:
+            t_rowptr, t_col, t_raw = _transpose_by_sort(rowptr, col, raw, C_, num_genes, support_mask)
         t_val, t_inv = _normalize_on_device(t_rowptr, t_raw)
         thost = t_rowptr.cpu().numpy()
         gc = AggCsr(t_rowptr, t_col, t_val, t_inv, num_genes, C_, build_plan(thost, chunk, device=dev), thost)

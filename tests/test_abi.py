@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in wgnn.h but not exported"
         assert s in _lib.SIGNATURES, f"{s} has no ctypes signature in _lib.py"
-    assert lib.wgnn_version() == 205 and lib.wgnn_version() >= _lib.ABI_MIN
+    assert lib.wgnn_version() == 206 and lib.wgnn_version() >= _lib.ABI_MIN
     assert b"ok" == lib.wgnn_last_error_string(0)
 
 
@@ -84,6 +84,16 @@ def test_argument_validation_returns_error_codes_without_gpu():
     assert fill(waves=5) == -1 and fill(kb=300) == -1 and fill(n_flat=2 ** 31) == -3
     assert fill(seg_ptr=None) == -1 and fill(entries=None) == -1 and fill(val=None) == -1
     assert fill(n_flat=0) == 0
+    # stable CSR transpose (0.2.6): counters for <= 32768 columns, everything else is the caller's sort
+    n_ch, n_b = C.c_int64(), C.c_int64()
+    assert lib.wgnn_csr_transpose_workspace(100000, 20000, C.addressof(n_ch), C.addressof(n_b)) == 0
+    assert n_ch.value == 512 and n_b.value == 512 * 20000 * 4
+    assert lib.wgnn_csr_transpose_workspace(100, 50, C.addressof(n_ch), C.addressof(n_b)) == 0 and n_ch.value == 1
+    assert lib.wgnn_csr_transpose_workspace(100, 40000, C.addressof(n_ch), C.addressof(n_b)) == -3
+    assert lib.wgnn_csr_transpose_workspace(-1, 5, C.addressof(n_ch), C.addressof(n_b)) == -1
+    assert lib.wgnn_csr_transpose_count(None, one, None, 4, 8, 1, one, one, None) == -1
+    assert lib.wgnn_csr_transpose_count(one, one, None, 4, 40000, 1, one, one, None) == -3
+    assert lib.wgnn_csr_transpose_fill(one, one, None, None, 4, 8, 1, one, one, one, one, None) == -1
     for code in (-1, -2, -3, -4, -5, -6):
         assert len(lib.wgnn_last_error_string(code)) > 3
 

@@ -2750,3 +2750,34 @@ def test_unsorted_device_csr_gives_the_sorted_result():
     dup_col = col.clone(); dup_col[1] = dup_col[0]
     with pytest.raises(ValueError, match="more than once"):
         sda.CellGeneGraph.from_device_csr(rp, dup_col, val, G)
+
+
+@pytest.mark.parametrize("cells,genes,density", [(5000, 1200, 0.05), (300, 90, 0.4), (70, 2500, 0.6), (20000, 400, 0.02)])
+def test_csr_transpose_kernel_matches_the_sort_path(cells, genes, density):
+    """Round 6: `wgnn_csr_transpose_count` / `_fill` (csrc/wgnn_transpose.hip: per-chunk LDS histograms + an in-order walk, no sort)
+    against the framework path (bincount, stable radix sort, two gathers): bit-identical gene-major copies - with and without a
+    support mask (predict graphs: preprocess.py:184-187), empty cells and genes, a cell with more than 1024 genes, few and many
+    chunks - and therefore identical graphs."""
+    from scdeepsort_amd import graph as GR, synthetic as S
+    rp, col, val = S.synth_expression(cells, genes, density, seed=cells + genes, device=DEV)
+    rp32 = rp.to(torch.int32)
+    mask = torch.rand(cells, device=DEV) < 0.6
+    mask[: min(5, cells)] = False
+    for m in (None, mask, torch.zeros(cells, dtype=torch.bool, device=DEV)):
+        a = GR._transpose_on_device(rp32, col, val, cells, genes, m)
+        b = GR._transpose_by_sort(rp32, col, val, cells, genes, m)
+        for x, y in zip(a, b):
+            assert x.dtype == y.dtype and torch.equal(x, y)
+    saved = GR.CSR_TRANSPOSE_KERNEL
+    graphs = {}
+    try:
+        for kern in (True, False):
+            GR.CSR_TRANSPOSE_KERNEL = kern
+            graphs[kern] = sda.CellGeneGraph.from_device_csr(rp, col, val, genes, support_mask=mask)
+            graphs[kern].cg.transposed()
+    finally:
+        GR.CSR_TRANSPOSE_KERNEL = saved
+    for name in ("rowptr", "col", "val", "inv_deg"):
+        assert torch.equal(getattr(graphs[True].gc, name), getattr(graphs[False].gc, name)), name
+        assert torch.equal(getattr(graphs[True].cg._t, name), getattr(graphs[False].cg._t, name)), name
+    assert GR.CSR_TRANSPOSE_KERNEL                                   # the kernel is the default on the GPU
