@@ -1,20 +1,21 @@
-// wgnn_plan.hip - device-side construction of the tile plan's `entries` (round 5).
+// wgnn_plan.hip - device-side construction of the tile plan's `entries` (round 5; rebuilt in round 6).
 //
 // The tile plan re-orders the CSR into (tile, LDS block, wave) segments with the layout [unshared][pad][shared pairs]
 // (include/wgnn.h, wgnn_agg_fwd_tiled).  Rounds 1-4 built it with framework index arithmetic: two stable sorts and ~40
 // element-wise passes over 8e7 non-zeros, ~90 ms per direction at BASELINE cfg3 (18-22 ms after round 5's trimming) - more
 // than ten forwards, paid by every one-shot inference (the reference builds a graph per prediction, predict.py:44-54).
 // The structure makes a sort unnecessary: a (tile, wave) pair owns <= 64 destination rows whose non-zeros are already
-// sorted by column, so ONE wavefront per (tile, wave) - lane = destination slot - walks its rows in lock step through
-// the tile's source range: per LDS block it repeatedly takes the smallest pending column (a wave minimum), finds the lanes
-// that hold it (a ballot = the group of entries on that source row), and knows every entry's place in the segment from
-// running counts.  Round 6: the COUNT pass no longer walks groups.  A segment is padded to an EVEN number of entries whenever its
-// entry count is odd (the pair count is even, so "odd unshared run" == "odd total": the pad costs no pair step, an odd chunk has
-// an idle half step anyway), which makes a segment's size a function of its entry count alone - and that needs only every
-// lane stepping through ITS row once per block (no wave minimum, no ballot): ~10x fewer instructions than the group walk.  FILL
-// (after the prefix sum over the segments) places the unshared entries from the segment's start upwards and the shared pairs
-// from its end DOWNWARDS, so it needs no pair count either; the pad lands between them.
-// No atomics, deterministic.  Reference counterpart: none (DGL built its own CSR, preprocess_internal.py:215).
+// sorted by column, so ONE wavefront per (tile, wave, block range) - lane = destination slot - can place them.  Round 5 walked
+// the rows in lock step, one source-row group at a time (a wave minimum of the pending columns, a ballot, running counts), twice:
+// 9.8 / 12.4 ms per plan.  Round 6:
+//   COUNT - a segment is padded to an EVEN number of entries whenever its entry count is odd (the pair count is even, so "odd
+//           unshared run" == "odd total": the pad costs no pair step, an odd chunk has an idle half step anyway), so a segment's
+//           size is a function of its entry count alone: an LDS histogram of the wave's rows' columns over the tile's blocks,
+//           filled entry-parallel from coalesced reads (tile_plan_count).
+//   FILL  - per LDS block: a bitmap of slots per source row (ds_or), one wave scan over the source rows for the groups' offsets,
+//           entry-parallel placement from a ballot-appended entry list (tile_plan_fill).
+// 3.2 / 4.1 ms per plan.  No atomics on global memory, deterministic.  Reference counterpart: none (DGL built its own CSR,
+// preprocess_internal.py:215).
 #include <climits>
 #include "wgnn_common.h"
 
@@ -36,32 +37,9 @@ struct PlanArgs {
     const int* seg_ptr; int2* entries;          // FILL: [n_seg + 1] offsets (prefix sum of seg_total rounded up to even), output
 };
 
-// Minimum over the 64 lanes, on the VALU's data-parallel primitives (row shifts inside a row of 16, then the row broadcasts of
-// gfx9): ~8 instructions and no LDS traffic.  (The shuffle form - six ds_bpermute per call - made the LDS pipe the bottleneck
-// of the whole walk: 4.6 + 7.1 ms for the two passes at cfg3.)
-__device__ __forceinline__ int wave_min(int v) {
-    v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x111, 0xf, 0xf, false));     // row_shr:1
-    v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x112, 0xf, 0xf, false));     // row_shr:2
-    v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x114, 0xf, 0xf, false));     // row_shr:4
-    v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x118, 0xf, 0xf, false));     // row_shr:8  -> lane 15 of a row: its minimum
-    v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x142, 0xa, 0xf, false));     // row_bcast:15 into rows 1 and 3
-    v = min(v, __builtin_amdgcn_update_dpp(INT_MAX, v, 0x143, 0xc, 0xf, false));     // row_bcast:31 into rows 2 and 3
-    return __builtin_amdgcn_readlane(v, 63);
-}
-
-// Sum over the 64 lanes, same data-parallel primitives (a row-wise inclusive scan, then the row broadcasts).
-__device__ __forceinline__ int wave_sum(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);     // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);     // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);     // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);     // row_shr:8  -> lane 15 of a row: its sum
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
-    return __builtin_amdgcn_readlane(v, 63);
-}
-
-// Inclusive -> exclusive scan over the 64 lanes (row-wise inclusive scan by row shifts, rows chained through the row
-// broadcasts); returns the exclusive prefix of `v`, `total` = the wave's sum.
+// Exclusive scan over the 64 lanes on the VALU's data-parallel primitives - a row-wise inclusive scan by row shifts, the rows
+// chained through the row broadcasts of gfx9 (~8 instructions, no LDS traffic; the shuffle form - six ds_bpermute per call -
+// made the LDS pipe the bottleneck of round 5's first walk); returns the exclusive prefix of `v`, `total` = the wave's sum.
 __device__ __forceinline__ int wave_excl_scan(int v, int& total) {
     int x = v;
     x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false);     // row_shr:1
