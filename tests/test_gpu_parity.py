@@ -2781,3 +2781,23 @@ def test_csr_transpose_kernel_matches_the_sort_path(cells, genes, density):
         assert torch.equal(getattr(graphs[True].gc, name), getattr(graphs[False].gc, name)), name
         assert torch.equal(getattr(graphs[True].cg._t, name), getattr(graphs[False].cg._t, name)), name
     assert GR.CSR_TRANSPOSE_KERNEL                                   # the kernel is the default on the GPU
+
+
+def test_more_genes_than_the_transpose_kernel_counts_take_the_sort_path():
+    """`wgnn_csr_transpose_*` keeps one LDS counter per gene (<= 32768); a wider operand is transposed by the framework path - same
+    graph as the oracle's, forward through the row-wave kernel."""
+    from scdeepsort_amd import graph as GR, synthetic as S
+    C, G, D = 400, 40000, 32
+    rp, col, val = S.synth_expression(C, G, 0.002, seed=9, device=DEV)
+    with pytest.raises(Exception):
+        GR._transpose_on_device(rp.to(torch.int32), col, val, C, G, None)            # WGNN_ERR_UNSUPPORTED, loudly
+    g = sda.CellGeneGraph.from_device_csr(rp, col, val, G)
+    expr = S.to_scipy(rp, col, val, G)
+    cg = O.build_csr_graph(expr)
+    alpha = np.random.default_rng(1).uniform(0.5, 1.5, G + 2).astype(np.float32)
+    feats = np.random.default_rng(2).standard_normal((G + C, D)).astype(np.float32)
+    zc, zg = O.csr_aggregate(cg, alpha, feats[:G].astype(np.float64), feats[G:].astype(np.float64))
+    out_g = sda.agg_fwd(g.gc, dev(alpha), sda.DST_IS_GENE, G, dev(feats[G:]), dev(feats[:G]))
+    out_c = sda.agg_fwd(g.cg, dev(alpha), sda.SRC_IS_GENE, G + 1, dev(feats[:G]), dev(feats[G:]))
+    np.testing.assert_allclose(out_g.cpu().numpy(), zg, atol=TOL)
+    np.testing.assert_allclose(out_c.cpu().numpy(), zc, atol=TOL)
