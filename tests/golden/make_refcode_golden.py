@@ -191,6 +191,10 @@ def make_case(name, gnn_mod, pre_mod, expr, support_mask, dim, hidden, n_classes
 
 
 def main():
+    # one thread, deterministic kernels: the wide case's scatter-adds (the stand-in's fn.mean and its backward) are summed in
+    # thread-dependent order otherwise, and a re-run would differ from the committed file in the last bits
+    torch.set_num_threads(1)
+    torch.use_deterministic_algorithms(True)
     install_dgl_standin()
     gnn_mod = load(REF / "models" / "gnn.py", "ref_gnn")
     pre_mod = load(REF / "utils" / "preprocess_internal.py", "ref_preprocess_internal")
