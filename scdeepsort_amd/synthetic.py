@@ -243,9 +243,36 @@ def _synth_expression_dense_head(cells, genes, density, seed, device, shuffle_ge
 
 
 def synth_features(n_nodes: int, dim: int, seed: int = REFERENCE_SEED + 1, device="cpu",
-                   dtype=torch.float32) -> torch.Tensor:
-    gen = torch.Generator(device=torch.device(device)).manual_seed(seed)
-    return (0.5 * torch.randn(n_nodes, dim, generator=gen, device=device)).to(dtype)
+                   dtype=torch.float32, rng: str | None = None) -> torch.Tensor:
+    """Node features ~ 0.5 * N(0, 1), fp32 or fp16 storage.  ``rng="numpy"`` (default with the testis199 law):
+    ``numpy.random.default_rng(seed)`` on the host - the same rows on every machine, with or without a GPU; blocks of 65 536 rows
+    from child streams, so the result does not depend on the thread count.  ``rng="torch"`` (the dense_head A/B workload of rounds
+    1-5): torch's generator on the target device."""
+    rng = rng or ("torch" if os.environ.get("WGNN_SYNTH_POPULARITY", "testis199") == "dense_head" else "numpy")
+    if rng == "torch":
+        gen = torch.Generator(device=torch.device(device)).manual_seed(seed)
+        return (0.5 * torch.randn(n_nodes, dim, generator=gen, device=device)).to(dtype)
+    if rng != "numpy":
+        raise ValueError(f"unknown feature rng {rng!r} (numpy | torch)")
+    block = 65536
+    starts = list(range(0, n_nodes, block))
+    children = np.random.default_rng(seed).spawn(len(starts))
+    out = np.empty((n_nodes, dim), dtype=np.float32)
+
+    def fill(i):
+        r0 = starts[i]
+        n = min(block, n_nodes - r0)
+        children[i].standard_normal(size=(n, dim), dtype=np.float32, out=out[r0:r0 + n])
+
+    nthreads = min(_host_threads(), len(starts))
+    if nthreads > 1:
+        with ThreadPoolExecutor(nthreads) as pool:
+            list(pool.map(fill, range(len(starts))))
+    else:
+        for i in range(len(starts)):
+            fill(i)
+    out *= 0.5
+    return torch.from_numpy(out).to(device=torch.device(device), dtype=dtype)
 
 
 def to_scipy(rowptr: torch.Tensor, col: torch.Tensor, val: torch.Tensor, genes: int):

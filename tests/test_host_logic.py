@@ -529,3 +529,21 @@ def test_synthetic_cell_range_is_a_slice_of_the_whole_matrix(monkeypatch):
     import os
     cores = len(os.sched_getaffinity(0))
     assert S._host_threads() == max(1, min(64, cores // 8))
+
+
+def test_synthetic_features_come_from_numpy_default_rng():
+    """node features ~ 0.5 * N(0, 1) from numpy.random.default_rng(seed) - the same rows on every machine, independent
+    of the thread count (blocks of 65 536 rows from child streams); fp16 storage for cfg5; the torch device generator is kept for
+    the dense_head A/B workload only."""
+    a = S.synth_features(70_000, 12, seed=7)
+    assert a.dtype == torch.float32 and a.shape == (70_000, 12)
+    assert abs(float(a.mean())) < 5e-3 and abs(float(a.std()) - 0.5) < 5e-3
+    assert torch.equal(a, S.synth_features(70_000, 12, seed=7)) and not torch.equal(a, S.synth_features(70_000, 12, seed=8))
+    assert torch.equal(a[:65_536], S.synth_features(65_536, 12, seed=7))            # a block does not depend on the ones behind it
+    want = 0.5 * np.random.default_rng(7).spawn(2)[0].standard_normal(size=(65_536, 12), dtype=np.float32)
+    assert np.array_equal(a[:65_536].numpy(), want)
+    assert S.synth_features(100, 8, seed=1, dtype=torch.float16).dtype == torch.float16
+    t = S.synth_features(100, 8, seed=1, rng="torch")
+    assert t.shape == (100, 8) and not torch.equal(t, S.synth_features(100, 8, seed=1))
+    with pytest.raises(ValueError):
+        S.synth_features(4, 4, rng="nope")
