@@ -54,7 +54,9 @@ def _worker(rank, world, port, out_dir, hidden, dropout, backend=BACKEND, force=
         m = sda.GNN(Din, hidden, ncls, n_layers, G, activation=F.relu, dropout=dropout).to(dev)
         with torch.no_grad():
             m.alpha.uniform_(0.5, 1.5)
-        feats = S.synth_features(G + C, Din, device=dev)
+        # (the torch-generator features this test's tolerances were calibrated on: a gradient check against an fp64 oracle is
+        #  sensitive to pre-activations that round to different sides of the ReLU, i.e. to the particular inputs)
+        feats = S.synth_features(G + C, Din, device=dev, rng="torch")
         lo, hi = D.shard_range(C, rank, world)
         b, e = int(rp[lo]), int(rp[hi])
         eng = ShardedWgnn.build(m, (rp[lo:hi + 1] - rp[lo]).clone(), col[b:e].clone(), val[b:e].clone(), G, seed=11)
